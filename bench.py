@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline metric on MI355X: shaded Mpixels/s of the 4K deferred frame (BuildHZB +
+CullIndirectArgs + DeferredLighting/Sky) on the Sponza constants, with % of HBM roofline for the dominant kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one frame of BASELINE.json configs[2] on synthetic inputs already resident in HBM:
+  cull (Sponza's 25 commands, last frame's HZB) -> BuildHZB (full chain) -> DeferredLighting+Sky (fused kernel).
+N > 1: the frame is sharded by screen row bands (rank r shades rows [r*H/N,(r+1)*H/N)), the cull by instance ranges, the
+HZB build is replicated, and the HDR bands are all-gathered with RCCL (torch.distributed backend "nccl") every frame.
+Rank 0 prints ONE JSON line. The CPU oracle is used only for the cpu_baseline leg (rank 0, N == 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--gbuffer", choices=["scene", "iid"], default="scene")
+    ap.add_argument("--ring", type=int, default=4, help="distinct frame-buffer sets cycled through so inputs are cache-cold")
+    ap.add_argument("--cull-instances", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 1M-instance cull and iid side measurements")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import HotPath, HzbLayout, to_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    W, H, N = args.width, args.height, world
+    if H % N != 0:
+        raise SystemExit(f"height {H} not divisible by {N} ranks")
+    band = H // N
+    row0 = rank * band
+    hp = HotPath(local_rank)
+    dev = local_rank
+
+    # ---------------- inputs (synthetic, generated per rank for its own band; constants from the shipped Sponza scene)
+    preset = hostmath.SCENES["sponza"]
+    fc = hostmath.build_frame_constants(preset, W, H, shadow_size=2048, env_mip_count=9)
+    seed = synth.SEED_BASE + 3
+    t_gen = time.time()
+    if args.gbuffer == "scene":
+        g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, W, H, seed, row0, band)
+        shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+    else:
+        g = synth.gbuffer_iid(W, H, seed, row0, band)
+        shadow = synth.shadow_map_noise(2048, seed)
+    # HZB build is replicated: every rank needs the full-frame depth
+    if N == 1:
+        depth_full = g.depth
+    elif args.gbuffer == "scene":
+        depth_full = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, W, H, seed).depth
+    else:
+        depth_full = synth.gbuffer_iid(W, H, seed).depth
+    env = synth.env_cube_procedural(256, 9, sun_dir=fc.light_direction)
+    lut = synth.brdf_lut_procedural(128, 32)
+    gen_s = time.time() - t_gen
+
+    tables = hp.make_tables(to_device(shadow, dev), hp.stage_env_cube(env, 256, 9), 256, 9, to_device(lut, dev))
+    lay = HzbLayout(W, H)
+    ring = max(1, args.ring)
+    sets = []
+    for _ in range(ring):
+        s = {
+            "A": to_device(g.A, dev), "B": to_device(g.B, dev), "C": to_device(g.C, dev),
+            "depth_full": to_device(depth_full, dev),
+            "hdr_full": torch.zeros((H, W, 4), dtype=torch.int16, device=f"cuda:{dev}"),
+            "hzb": torch.zeros(lay.total, dtype=torch.float32, device=f"cuda:{dev}"),
+        }
+        s["hdr_full"][row0:row0 + band] = to_device(g.hdr, dev)
+        s["depth_band"] = s["depth_full"][row0:row0 + band]
+        # N == 1: shade straight into the frame; N > 1: shade a band buffer, RCCL gathers the bands into the frame
+        s["hdr_band"] = s["hdr_full"][row0:row0 + band] if N == 1 else to_device(g.hdr, dev)
+        sets.append(s)
+
+    # Sponza cull: 25 commands sharing one AABB, sharded by instance range
+    n_inst = preset.instance_count
+    i0, i1 = rank * n_inst // N, (rank + 1) * n_inst // N
+    bounds = synth.instances_replicated(*preset.model_aabb, n_inst)[i0:i1]
+    d_bounds = to_device(bounds, dev) if i1 > i0 else None
+    d_args = to_device(synth.indirect_args_initial(n_inst)[i0:i1], dev) if i1 > i0 else None
+    d_vis = torch.zeros(max(1, i1 - i0), dtype=torch.int32, device=f"cuda:{dev}")
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=f"cuda:{dev}")
+    cull_consts = hostmath.pack_culling_constants(fc.view, fc.proj, i1 - i0, True, lay.count, lay.width, lay.height, False)
+
+    light_events = []
+
+    def step(k: int, timed: bool):
+        s = sets[k % ring]
+        prev = sets[(k - 1) % ring]
+        # GPU Culling reads LAST frame's HZB (DeferredRenderer.cpp:519-542)
+        hp.cull_indirect_args(cull_consts, d_bounds, prev["hzb"], lay, d_args, None, d_vis, d_cnt, i0)
+        hp.build_hzb(s["depth_full"], s["hzb"], lay)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hp.deferred_lighting_sky(fc.scene, fc.sky, s["A"], s["B"], s["C"], s["depth_band"], tables, s["hdr_band"], W, H, row0, band)
+        if timed:
+            e1.record()
+            light_events.append((e0, e1))
+        if N > 1:
+            dist.all_gather_into_tensor(s["hdr_full"].view(-1), s["hdr_band"].reshape(-1))
+
+    def fence():
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k, False)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, True)
+    fence()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    light_ms = np.array([a.elapsed_time(b) for a, b in light_events], dtype=np.float64)
+    n_sky = int((g.depth == 0).sum())
+    n_geo = g.depth.size - n_sky
+    # algorithmic bytes of one fused launch on this rank: geometry pixels read A 8 + B 8 + C 4 + depth 4 + HDR 8 and write
+    # HDR 8 (= 40 B); sky pixels read depth 4 and write HDR 8 (= 12 B). Side tables are cache-resident and excluded.
+    light_bytes = 40 * n_geo + 12 * n_sky
+    light_avg_s = float(light_ms.mean()) * 1e-3
+    achieved = light_bytes / light_avg_s / 1e9
+
+    result = {
+        "metric": "shaded Mpixels/s, 4K deferred pass (BuildHZB + CullIndirectArgs + DeferredLighting/Sky), Sponza; % HBM roofline",
+        "value": W * H * args.steps / dt / 1e6,
+        "unit": "Mpixels/s",
+        "n_gpus": N,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32 math, fp16 G-buffer/HDR I/O",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Sponza {W}x{H} full pipeline: cull(25) + BuildHZB({lay.count} mips) + DeferredLighting+Sky fused"
+                        + (f", {N} row bands + RCCL all-gather of HDR" if N > 1 else ""),
+            "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
+            "ibl_tables": "procedural 256^2x9 cube + analytic LUT (shipped DDS not decoded yet)",
+            "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
+        },
+        "roofline": {
+            "kernel": "lighting_kernel<FUSED>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float(light_ms.min()) * 1e3,
+            "shade_only_mpixels_per_s": g.depth.size * N / light_avg_s / 1e6,
+        },
+    }
+    traffic_file = ROOT / "profiles" / "traffic_latest.json"
+    if traffic_file.exists():
+        try:
+            result["roofline"]["traffic"] = json.loads(traffic_file.read_text()).get("lighting_kernel_fused_bytes_per_launch")
+        except Exception:
+            pass
+
+    if rank == 0 and N == 1 and not args.no_extras:
+        result["extras"] = side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath, dev)
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(fc, g, shadow, env, lut, bounds, lay, W, H)
+    if rank == 0:
+        result["setup_seconds"] = round(gen_s, 1)
+        print(json.dumps(result))
+    if N > 1:
+        dist.destroy_process_group()
+
+
+def _time_events(torch, fn, iters, warm=5):
+    for _ in range(warm):
+        fn()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3
+    return float(np.median(t)), float(t.min())
+
+
+def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath, dev):
+    """Culled instances/s on BASELINE config 5's instance set (1 M AABBs against an 8K-frame HZB) and per-kernel times."""
+    out = {}
+    W8, H8 = 7680, 4320
+    n = args.cull_instances
+    fc8 = hostmath.build_frame_constants("sponza", W8, H8)
+    lay8 = HzbLayout(W8, H8)
+    depth8 = to_device(synth.gbuffer_scene(fc8.view, fc8.proj, fc8.camera_position, W8, H8, synth.SEED_BASE + 5).depth, dev)
+    hzb8 = torch.zeros(lay8.total, dtype=torch.float32, device=f"cuda:{dev}")
+    med, mn = _time_events(torch, lambda: hp.build_hzb(depth8, hzb8, lay8), 30)
+    hzb_bytes = 4 * (W8 * H8 + lay8.mip_texels())
+    out["build_hzb_8k"] = {"median_us": med * 1e6, "GBps": hzb_bytes / med / 1e9, "frac_hbm": hzb_bytes / med / 1e9 / HBM_PEAK_GBS}
+    bounds = to_device(synth.instances_random(n, synth.SEED_BASE + 5, center=fc8.camera_position, box=400.0), dev)
+    d_args = to_device(synth.indirect_args_initial(n), dev)
+    d_vis = torch.zeros(n, dtype=torch.int32, device=f"cuda:{dev}")
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=f"cuda:{dev}")
+    d_stats = torch.zeros(2, dtype=torch.int32, device=f"cuda:{dev}")
+    consts_dbg = hostmath.pack_culling_constants(fc8.view, fc8.proj, n, True, lay8.count, lay8.width, lay8.height, True)
+    hp.cull_indirect_args(consts_dbg, bounds, hzb8, lay8, d_args, d_stats, d_vis, d_cnt)
+    torch.cuda.synchronize()
+    frustum_culled, occluded = (int(v) for v in d_stats.cpu().numpy().view(np.uint32))
+    visible = int(d_cnt.cpu().numpy().view(np.uint32)[0])
+    consts = hostmath.pack_culling_constants(fc8.view, fc8.proj, n, True, lay8.count, lay8.width, lay8.height, False)
+    med, mn = _time_events(torch, lambda: hp.cull_indirect_args(consts, bounds, hzb8, lay8, d_args, None, d_vis, d_cnt), 50)
+    f_frustum = 1.0 - frustum_culled / n
+    cull_bytes = n * (36 + 16 * f_frustum) + 4 * visible
+    out["cull_1m"] = {"instances": n, "visible": visible, "frustum_culled": frustum_culled, "occluded": occluded,
+                      "median_us": med * 1e6, "instances_per_s": n / med, "algorithmic_GBps": cull_bytes / med / 1e9,
+                      "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
+def cpu_baseline(fc, g, shadow, env, lut, bounds, lay, W, H):
+    """The scalar C++ oracle (oracle/ur_oracle.cpp, -O2 -ffp-contract=off) timed on this box's host cores on one full
+    frame of the same workload. kind = "port": the reference's D3D12/HLSL cannot run here."""
+    from oracle import oracle as o
+    from unclerenderer_amd import hostmath, synth
+    o.build()
+    cores = o.hardware_threads()
+    o.set_threads(cores)
+    t0 = time.perf_counter()
+    hzb = o.build_hzb(g.depth, lay.as_list(), lay.total)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, bounds.shape[0], True, lay.count, lay.width, lay.height, False)
+    o.cull_indirect_args(consts, bounds, np.nan_to_num(hzb), lay.as_list(), synth.indirect_args_initial(bounds.shape[0]))
+    t1 = time.perf_counter()
+    lit = o.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 256, 9, lut, g.hdr, W, H)
+    o.sky_atmosphere(fc.sky, g.depth, lit, W, H)
+    t2 = time.perf_counter()
+    return {"value": W * H / (t2 - t0) / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"1 full {W}x{H} frame: BuildHZB+cull single-thread {t1 - t0:.2f}s, lighting+sky on {cores} threads {t2 - t1:.2f}s"}
+
+
+if __name__ == "__main__":
+    main()

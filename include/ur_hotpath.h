@@ -1,0 +1,209 @@
+/*
+ * ur_hotpath.h — C-ABI of the MI355X-native visibility + deferred-shading hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types. The entry points are
+ * what the four pass lambdas of the reference's FDeferredRenderer::RenderFrame would call instead of
+ * recording D3D12 commands (reference: Source/Render/DeferredRenderer.cpp:522-542 cull,
+ * :998-1211 Build HZB, :1219-1255 Lighting, :1263-1296 Sky; Source/Render/Renderer.cpp:394-472).
+ *
+ * Conventions
+ *  - return UR_OK (0) or a negative UR_E* code; ur_last_error() gives a thread-local message;
+ *  - every pointer documented "device" is caller-owned HIP device memory; "host" is host memory
+ *    read synchronously during the call (constant blocks are passed by value to the kernels, exactly
+ *    like D3D12 root constants / a mapped CBV);
+ *  - all launches are asynchronous on the stream given to ur_create(); no call synchronises;
+ *  - images are linear row-major, pitch == width (no D3D swizzle);
+ *  - matrices are row-major, row-vector convention (mul(v, M)) — the reference compiles every shader
+ *    with -Zpr (Source/Render/ShaderCompiler.cpp:74);
+ *  - screen-tile sharding: image buffers passed to the shading entry points are BAND-LOCAL: they hold
+ *    rows [row0, row0+rows) of a frame of full size (w, h). For a whole frame pass row0=0, rows=h.
+ */
+#ifndef UR_HOTPATH_H
+#define UR_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UR_OK 0
+#define UR_EINVAL (-1)       /* bad argument (null pointer, zero size, inconsistent layout) */
+#define UR_EHIP (-2)         /* a HIP runtime call failed */
+#define UR_ENOMEM (-3)       /* workspace allocation failed */
+#define UR_ENODEVICE (-4)    /* no usable gfx950 device */
+#define UR_EUNSUPPORTED (-5) /* valid request outside what the kernels implement */
+
+#define UR_MAX_HZB_MIPS 16u
+#define UR_CULL_CONSTANT_DWORDS 46u
+#define UR_INDIRECT_COMMAND_STRIDE 64u        /* sizeof(FIndirectDrawCommand), RendererUtils.h:102-111 */
+#define UR_INDIRECT_INSTANCE_COUNT_OFFSET 44u /* CullIndirectArgs.hlsl:21-22 */
+
+typedef struct ur_ctx ur_ctx;
+
+typedef struct ur_float4 { float x, y, z, w; } ur_float4;
+/* four IEEE binary16 bit patterns (DXGI_FORMAT_R16G16B16A16_FLOAT texel) */
+typedef struct ur_half4 { uint16_t x, y, z, w; } ur_half4;
+
+/* One HZB mip inside a single linear R32F allocation (replaces the D3D12 subresource). */
+typedef struct ur_mip_desc {
+    uint32_t offset; /* in floats from hzb_base */
+    uint32_t width;
+    uint32_t height;
+} ur_mip_desc;
+
+/* FSceneConstants, byte-for-byte (Source/Render/RendererUtils.h:41-79 == Shaders/SceneConstants.hlsl:1-39). */
+typedef struct ur_scene_constants {
+    float World[16];
+    float View[16];
+    float ViewInverse[16];
+    float Projection[16];
+    float BaseColor[3];
+    float LightIntensity;
+    float LightDirection[3];
+    float Padding1;
+    float CameraPosition[3];
+    float Padding2;
+    float LightColor[3];
+    float Padding3;
+    float EmissiveFactor[3];
+    float Padding4;
+    float LightViewProjection[16];
+    float ShadowStrength;
+    float ShadowBias;
+    float ShadowMapSize[2];
+    float MetallicFactor;
+    float RoughnessFactor;
+    float BaseColorAlpha;
+    float AlphaCutoff;
+    uint32_t AlphaMode;
+    uint32_t PaddingMaterial[3];
+    float BaseColorTransformOffsetScale[4];
+    float BaseColorTransformRotation[4];
+    float MetallicRoughnessTransformOffsetScale[4];
+    float MetallicRoughnessTransformRotation[4];
+    float NormalTransformOffsetScale[4];
+    float NormalTransformRotation[4];
+    float EmissiveTransformOffsetScale[4];
+    float EmissiveTransformRotation[4];
+    float EnvMapMipCount;
+    float PaddingEnvMap[3];
+    uint32_t ObjectId;
+    float PaddingObjectId[3];
+} ur_scene_constants; /* 608 bytes */
+
+/* FSkyAtmosphereConstants (Source/Render/RendererUtils.h:81-92 == Shaders/SkyAtmosphere.hlsl:16-27). */
+typedef struct ur_sky_constants {
+    float World[16]; /* scale(R) * translate(camera), DeferredRenderer.cpp:3789-3801 */
+    float View[16];
+    float Projection[16];
+    float CameraPosition[3];
+    float Padding0;
+    float LightDirection[3];
+    float Padding1;
+    float LightColor[3];
+    float Padding2;
+} ur_sky_constants; /* 240 bytes */
+
+/* Read-only side tables of the lighting pass (t3..t5 of DeferredLighting.hlsl:11-16). All device. */
+typedef struct ur_lighting_tables {
+    const float* shadow_map;       /* ShadowMapSize.x * ShadowMapSize.y R32F; may be NULL iff ShadowStrength <= 0 */
+    const ur_half4* env_cube;      /* bordered cube written by ur_stage_env_cube() */
+    uint32_t env_base_size;        /* edge of mip 0 (256 for Assets/Textures/output_pmrem.dds) */
+    uint32_t env_mip_count;        /* mips present in env_cube (9) */
+    const uint16_t* brdf_lut_rg16; /* lut_width * lut_height texels, 2 x UNORM16 each (PreintegratedGF.dds) */
+    uint32_t lut_width;            /* 128: NdotV axis */
+    uint32_t lut_height;           /* 32: roughness axis */
+} ur_lighting_tables;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+
+/* Bind to HIP device `device` and launch on `stream` (a hipStream_t, NULL = default stream).
+ * Replaces FDX12CommandContext as the thing a pass lambda records into (RHI/DX12CommandContext.h:10-43). */
+ur_ctx* ur_create(int device, void* stream);
+void ur_destroy(ur_ctx* ctx);
+/* Pre-size the compaction workspace so later calls allocate nothing (graph-capture safe). */
+int ur_reserve(ur_ctx* ctx, uint32_t max_instances);
+const char* ur_last_error(void);
+const char* ur_version(void);
+
+/* ---- BuildHZB (Shaders/BuildHZB.hlsl:34-126, DeferredRenderer.cpp:1016-1211, :2801-2835) ------- */
+
+/* HZB sizing of CreateHZBResources: base = (max(1,(w+1)/2), max(1,(h+1)/2)), halve with max(1,d/2)
+ * until 1x1. Fills mips[0..*mip_count) with packed offsets; returns the total number of floats
+ * (0 on bad arguments). */
+uint32_t ur_hzb_layout(uint32_t src_w, uint32_t src_h, ur_mip_desc* mips /*host, UR_MAX_HZB_MIPS*/,
+                       uint32_t* mip_count);
+
+/* depth: device, src_w*src_h floats (the depth buffer as the SRV sees it: reverse-Z in [0,1]).
+ * hzb_base: device, laid out by `mips` (host). Builds every mip; values are bit-identical to the
+ * reference's dispatch chain of <=4 mips per dispatch, including its out-of-range fill quirks. */
+int ur_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base,
+                 const ur_mip_desc* mips, uint32_t mip_count);
+
+/* ---- CullIndirectArgs (+ visible-list compaction) ---------------------------------------------- */
+
+/* constants: host, the 46 root constants packed by FRenderer::DispatchGpuCulling (Renderer.cpp:411-429):
+ *   dw 0-23 FrustumPlanes[6], 24-39 ViewProjection (row-major), 40 ModelCount, 41 HZBEnabled,
+ *   42 HZBMipCount, 43 HZBWidth, 44 HZBHeight, 45 DebugPrintEnabled.
+ * bounds: device, 2*ModelCount float4 (min.xyz,_)(max.xyz,_) (CullIndirectArgs.hlsl:13,141-143).
+ * hzb_base/mips: as produced by ur_build_hzb (mips host); ignored when HZBEnabled == 0.
+ * indirect_args: device, ModelCount * 64 B; only the u32 at byte 44 of each command is written (0|1).
+ * stats2: device u32[2] or NULL — [0] += frustum-culled, [1] += occluded when DebugPrintEnabled != 0
+ *         (DebugPrintStats byte offsets 0 and 4, CullIndirectArgs.hlsl:156-166).
+ * visible_idx / visible_count: device or NULL (both or neither) — NEW: ascending list of instance
+ *         indices whose InstanceCount word is 1, and its length. Deterministic (no atomics-append).
+ * index_base (_ex only): added to every emitted index, for instance-range sharding across ranks. */
+int ur_cull_indirect_args(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
+                          const float* hzb_base, const ur_mip_desc* mips, void* indirect_args,
+                          uint32_t* stats2, uint32_t* visible_idx, uint32_t* visible_count);
+int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
+                             const float* hzb_base, const ur_mip_desc* mips, void* indirect_args,
+                             uint32_t* stats2, uint32_t* visible_idx, uint32_t* visible_count,
+                             uint32_t index_base);
+
+/* ---- DeferredLighting / SkyAtmosphere ---------------------------------------------------------- */
+
+/* Number of half4 texels of the bordered cube for (base_size, mip_count); 0 on bad arguments. */
+size_t ur_env_cube_texels(uint32_t base_size, uint32_t mip_count);
+/* Stage an RGBA16F cube in DDS order (face-major, mips inner; TextureLoader.cpp:276-315) from HOST
+ * memory into the device layout the lighting kernel samples: mip-major, 6 faces per mip, each face
+ * (N+2)x(N+2) with a one-texel border holding the seamless neighbours from the adjacent faces.
+ * dst_device must hold ur_env_cube_texels() texels. Synchronous (setup time, like the DDS upload). */
+int ur_stage_env_cube(ur_ctx* ctx, const ur_half4* src_host, uint32_t base_size, uint32_t mip_count,
+                      ur_half4* dst_device);
+
+/* DeferredLighting.hlsl:35-94 over rows [row0,row0+rows) of a w x h frame, additively blended
+ * (ONE/ONE, colour and alpha; DeferredRenderer.cpp:1997-2005) into hdr_inout.
+ * gbuf_a: (view normal.xyz, -viewZ) RGBA16F; gbuf_b: (specular, metallic, roughness, 1) RGBA16F;
+ * gbuf_c: R8G8B8A8_UNORM_SRGB (R in the low byte); hdr_inout: RGBA16F holding (emissive, 1).
+ * Like the reference it shades EVERY pixel, so cleared G-buffer pixels come out NaN. */
+int ur_deferred_lighting(ur_ctx* ctx, const ur_scene_constants* scene, const ur_half4* gbuf_a,
+                         const ur_half4* gbuf_b, const uint32_t* gbuf_c, const ur_lighting_tables* tables,
+                         ur_half4* hdr_inout, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows);
+
+/* SkyAtmosphere.hlsl:29-101 restated per pixel: the inside-out sphere of radius World[0] centred on
+ * the camera covers every pixel at depth Near / (R * dir_view.z); colour (sky, 1) is written, no
+ * blend, where that depth >= depth[pixel] (GREATER_EQUAL, DeferredRenderer.cpp:361-365). */
+int ur_sky_atmosphere(ur_ctx* ctx, const ur_sky_constants* sky, const float* depth, ur_half4* hdr_inout,
+                      uint32_t w, uint32_t h, uint32_t row0, uint32_t rows);
+
+/* Lighting + Sky in one pass over the band: pixels the sky pass would overwrite skip the lighting
+ * math; every other pixel gets exactly ur_deferred_lighting's value. Result == the two calls above. */
+int ur_deferred_lighting_sky(ur_ctx* ctx, const ur_scene_constants* scene, const ur_sky_constants* sky,
+                             const ur_half4* gbuf_a, const ur_half4* gbuf_b, const uint32_t* gbuf_c,
+                             const float* depth, const ur_lighting_tables* tables, ur_half4* hdr_inout,
+                             uint32_t w, uint32_t h, uint32_t row0, uint32_t rows);
+
+/* ---- multi-GPU: gather the row bands of the HDR frame ------------------------------------------ */
+
+/* comm: an ncclComm_t (RCCL). hdr_full: device, w*h half4 on every rank; rank r has already written
+ * rows [r*h/n, (r+1)*h/n). In-place ncclAllGather on the ctx stream. Requires n | h. */
+int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, uint32_t h,
+                      uint32_t n_ranks, uint32_t rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UR_HOTPATH_H */

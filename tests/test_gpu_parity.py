@@ -1,0 +1,341 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact for the HZB, the InstanceCount words, the visible list and its count;
+max(1e-3, 1 fp16 ulp) per channel for the RGBA16F HDR target. The oracle is unpinned by the reference (no tests or
+golden vectors exist there); it is pinned by tests/test_oracle_*.py and tests/golden/.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import hdr_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BuildHZB
+# ---------------------------------------------------------------------------------------------------------------------
+HZB_SIZES = [(1, 1), (2, 2), (3, 5), (17, 9), (64, 64), (129, 67), (512, 512), (1920, 1080), (1000, 3), (5, 300), (2, 33), (4096, 16)]
+
+
+@pytest.mark.parametrize("w,h", HZB_SIZES)
+def test_build_hzb_bit_exact(hotpath, oracle, w, h):
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    torch = _torch()
+    rng = np.random.default_rng(1000 + w * 7 + h)
+    depth = rng.random((h, w), dtype=np.float32)
+    depth[rng.random((h, w)) < 0.1] = 0.0  # cleared pixels
+    lay = HzbLayout(w, h)
+    # sizing == CreateHZBResources (oracle restates it independently, packed)
+    packed, _ = oracle.hzb_layout(w, h)
+    assert [(m[1], m[2]) for m in packed] == [(m[1], m[2]) for m in lay.as_list()]
+    hzb = torch.full((lay.total,), float("nan"), dtype=torch.float32, device="cuda")
+    hotpath.build_hzb(to_device(depth), hzb, lay)
+    torch.cuda.synchronize()
+    got = hzb.cpu().numpy()
+    ref = oracle.build_hzb(depth, lay.as_list(), lay.total)
+    for (off, mw, mh) in lay.as_list():
+        a = got[off:off + mw * mh].view(np.uint32)
+        b = ref[off:off + mw * mh].view(np.uint32)
+        assert np.array_equal(a, b), f"mip {mw}x{mh} differs at {np.flatnonzero(a != b)[:8]}"
+    # nothing outside the mips is written
+    mask = np.ones(lay.total, bool)
+    for (off, mw, mh) in lay.as_list():
+        mask[off:off + mw * mh] = False
+    assert np.isnan(got[mask]).all()
+
+
+def test_build_hzb_rejects_bad_chain(hotpath):
+    from unclerenderer_amd import lib
+    from unclerenderer_amd.hotpath import HzbLayout
+    torch = _torch()
+    lay = HzbLayout(64, 64)
+    lay.mips[1].width += 1
+    d = torch.zeros(64 * 64, device="cuda")
+    hz = torch.zeros(lay.total + 64, device="cuda")
+    with pytest.raises(lib.UrError) as e:
+        hotpath.build_hzb(d, hz, lay)
+    assert e.value.code == lib.UR_EINVAL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CullIndirectArgs + compaction
+# ---------------------------------------------------------------------------------------------------------------------
+def _cull_case(hotpath, oracle, n, hzb_on, seed, w=480, h=270, debug=True, index_base=0, box=120.0):
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    torch = _torch()
+    fc = hostmath.build_frame_constants("sponza", w, h)
+    g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, seed)
+    lay = HzbLayout(w, h)
+    hzb_ref = oracle.build_hzb(g.depth, lay.as_list(), lay.total)
+    hzb_ref = np.nan_to_num(hzb_ref, nan=0.0)
+    bounds = synth.instances_random(n, seed, center=fc.camera_position, box=box)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, n, hzb_on, lay.count, lay.width, lay.height, debug)
+    args0 = synth.indirect_args_initial(n)
+    ref_args, ref_stats, ref_vis, ref_cnt = oracle.cull_indirect_args(consts, bounds, hzb_ref, lay.as_list(), args0, index_base)
+
+    d_args = to_device(args0)
+    d_stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    d_vis = torch.full((max(n, 1),), -1, dtype=torch.int32, device="cuda")
+    d_cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    hotpath.cull_indirect_args(consts, to_device(bounds), to_device(hzb_ref), lay, d_args, d_stats, d_vis, d_cnt, index_base)
+    torch.cuda.synchronize()
+    got_args = d_args.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_args, ref_args), "indirect args differ (InstanceCount words or bytes outside offset 44)"
+    cnt = int(d_cnt.cpu().numpy().view(np.uint32)[0])
+    assert cnt == ref_cnt
+    got_vis = d_vis.cpu().numpy().view(np.uint32)[:cnt]
+    assert np.array_equal(got_vis, ref_vis)
+    assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats)
+    # definition of the derived list
+    words = ref_args[:, 11]
+    assert np.array_equal(ref_vis, np.flatnonzero(words == 1).astype(np.uint32) + index_base)
+    return ref_cnt, ref_stats
+
+
+@pytest.mark.parametrize("n", [1, 25, 63, 64, 65, 170, 256, 257, 1023, 4097, 100_000])
+@pytest.mark.parametrize("hzb_on", [False, True])
+def test_cull_bit_exact(hotpath, oracle, n, hzb_on):
+    cnt, stats = _cull_case(hotpath, oracle, n, hzb_on, seed=7 + n)
+    if n >= 1023:
+        assert 0 < cnt < n, "the synthetic case must exercise both outcomes"
+        if hzb_on:
+            assert stats[1] > 0, "no instance was occlusion-culled: HZB path not exercised"
+
+
+def test_cull_index_base_and_no_list(hotpath, oracle):
+    _cull_case(hotpath, oracle, 5000, True, seed=99, index_base=123_456)
+    # visible list is optional: words only
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import to_device
+    fc = hostmath.build_frame_constants("sponza", 64, 36)
+    n = 700
+    bounds = synth.instances_random(n, 5, center=fc.camera_position, box=60.0)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, n, False, 0, 0, 0, False)
+    args0 = synth.indirect_args_initial(n)
+    ref_args, *_ = oracle.cull_indirect_args(consts, bounds, None, [], args0)
+    d_args = to_device(args0)
+    hotpath.cull_indirect_args(consts, to_device(bounds), None, None, d_args)
+    assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args)
+
+
+def test_cull_empty(hotpath):
+    from unclerenderer_amd import hostmath
+    torch = _torch()
+    fc = hostmath.build_frame_constants("sponza", 64, 36)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, False)
+    d_cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    d_vis = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hotpath.cull_indirect_args(consts, None, None, None, None, None, d_vis, d_cnt)
+    assert int(d_cnt.cpu()[0]) == 0
+
+
+def test_cull_sponza_25(hotpath, oracle):
+    """BASELINE config 3's actual cull: 25 commands sharing one AABB."""
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    p = hostmath.SCENES["sponza"]
+    fc = hostmath.build_frame_constants(p, 3840, 2160)
+    bounds = synth.instances_replicated(*p.model_aabb, p.instance_count)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, 25, False, 0, 0, 0, True)
+    args0 = synth.indirect_args_initial(25)
+    ref_args, ref_stats, ref_vis, ref_cnt = oracle.cull_indirect_args(consts, bounds, None, [], args0)
+    assert ref_cnt == 25  # the camera is inside the model's box
+    d_args = to_device(args0)
+    d_vis = torch.zeros(25, dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hotpath.cull_indirect_args(consts, to_device(bounds), None, None, d_args, None, d_vis, d_cnt)
+    assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args)
+    assert np.array_equal(d_vis.cpu().numpy().view(np.uint32), ref_vis)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DeferredLighting / SkyAtmosphere
+# ---------------------------------------------------------------------------------------------------------------------
+def _lighting_inputs(scene_name, w, h, seed, mode, shadow_size=256, shadow_strength=1.0):
+    from unclerenderer_amd import hostmath, synth
+    fc = hostmath.build_frame_constants(scene_name, w, h, shadow_size=shadow_size, shadow_strength=shadow_strength)
+    if mode == "iid":
+        g = synth.gbuffer_iid(w, h, seed)
+    else:
+        g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, seed)
+    shadow = synth.shadow_map_noise(shadow_size, seed)
+    env = synth.env_cube_procedural(32, 6)
+    lut = synth.brdf_lut_procedural(128, 32)
+    fc.scene.EnvMapMipCount = 6.0
+    return fc, g, shadow, env, lut
+
+
+def _device_tables(hotpath, shadow, env, lut, base=32, mips=6):
+    from unclerenderer_amd.hotpath import to_device
+    d_env = hotpath.stage_env_cube(env, base, mips)
+    return hotpath.make_tables(to_device(shadow) if shadow is not None else None, d_env, base, mips, to_device(lut))
+
+
+@pytest.mark.parametrize("mode", ["iid", "scene"])
+@pytest.mark.parametrize("scene_name", ["sponza", "duck"])
+def test_lighting_and_sky_parity(hotpath, oracle, mode, scene_name):
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    w, h = 256, 144
+    fc, g, shadow, env, lut = _lighting_inputs(scene_name, w, h, seed=11, mode=mode)
+    tables = _device_tables(hotpath, shadow, env, lut)
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+
+    # --- lighting only (every pixel, NaN on cleared pixels like the reference)
+    ref_l, fragile = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 32, 6, lut, g.hdr, w, h, want_fragile=True)
+    d_hdr = to_device(g.hdr)
+    hotpath.deferred_lighting(fc.scene, dA, dB, dC, tables, d_hdr, w, h)
+    torch.cuda.synchronize()
+    got_l = d_hdr.cpu().numpy().view(np.uint16)
+    nbad, worst, _ = hdr_mismatch(got_l, ref_l, exclude=fragile)
+    assert nbad == 0, f"lighting: {nbad} channel values beyond tolerance (worst excess {worst})"
+    assert fragile.mean() < 5e-3
+    bg = g.depth == 0
+    if bg.any():
+        assert np.isnan(got_l.view(np.float16)[bg][:, :3].astype(np.float32)).all(), "cleared pixels must shade to NaN"
+
+    # --- sky over the lit buffer
+    ref_s = oracle.sky_atmosphere(fc.sky, g.depth, ref_l, w, h)
+    hotpath.sky_atmosphere(fc.sky, dD, d_hdr, w, h)
+    torch.cuda.synchronize()
+    got_s = d_hdr.cpu().numpy().view(np.uint16)
+    nbad, worst, _ = hdr_mismatch(got_s, ref_s, exclude=fragile)
+    assert nbad == 0, f"sky: {nbad} beyond tolerance (worst {worst})"
+    assert not np.isnan(got_s.view(np.float16).astype(np.float32)[~fragile.astype(bool)]).any()
+
+    # --- fused == the two passes
+    d_hdr2 = to_device(g.hdr)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, d_hdr2, w, h)
+    torch.cuda.synchronize()
+    got_f = d_hdr2.cpu().numpy().view(np.uint16)
+    nbad, worst, _ = hdr_mismatch(got_f, ref_s, exclude=fragile)
+    assert nbad == 0, f"fused: {nbad} beyond tolerance (worst {worst})"
+    assert np.array_equal(got_f, got_s), "fused kernel must equal lighting followed by sky bit for bit"
+
+
+def test_lighting_without_shadows(hotpath, oracle):
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    w, h = 128, 64
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=3, mode="iid", shadow_strength=0.0)
+    tables = _device_tables(hotpath, None, env, lut)
+    ref = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, None, env, 32, 6, lut, g.hdr, w, h)
+    d_hdr = to_device(g.hdr)
+    hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, d_hdr, w, h)
+    torch.cuda.synchronize()
+    nbad, worst, _ = hdr_mismatch(d_hdr.cpu().numpy().view(np.uint16), ref)
+    assert nbad == 0, (nbad, worst)
+
+
+def test_row_bands_equal_whole_frame(hotpath):
+    """Screen-tile sharding: shading 4 bands separately gives the whole-frame result bit for bit."""
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    w, h = 320, 180
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=21, mode="scene")
+    tables = _device_tables(hotpath, shadow, env, lut)
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+    whole = to_device(g.hdr)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, whole, w, h)
+    parts = to_device(g.hdr)
+    for r in range(4):
+        r0, rows = r * 45, 45
+        sl = slice(r0, r0 + rows)
+        hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA[sl], dB[sl], dC[sl], dD[sl], tables, parts[sl], w, h, r0, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, parts)
+
+
+def test_stage_env_cube_matches_folding_rule(hotpath, oracle):
+    from unclerenderer_amd import synth
+    env = synth.env_cube_procedural(16, 5)
+    env[:, 0] = (np.arange(env.shape[0]) & 0x3FF).astype(np.uint16)  # make every texel distinguishable
+    got = hotpath.stage_env_cube(env, 16, 5).cpu().numpy().view(np.uint16)
+    ref = oracle.stage_env_cube(env, 16, 5)
+    assert np.array_equal(got, ref)
+
+
+def test_lighting_rejects_non_rigid_view(hotpath):
+    from unclerenderer_amd import lib
+    from unclerenderer_amd.hotpath import to_device
+    w, h = 16, 8
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=1, mode="iid")
+    tables = _device_tables(hotpath, shadow, env, lut)
+    fc.scene.ViewInverse[0] = 2.0
+    with pytest.raises(lib.UrError) as e:
+        hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, to_device(g.hdr), w, h)
+    assert e.value.code == lib.UR_EUNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full BASELINE sizes through size-independent properties
+# ---------------------------------------------------------------------------------------------------------------------
+def test_full_size_properties_4k(hotpath, oracle):
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    torch = _torch()
+    import torch.nn.functional as F
+    w, h = 3840, 2160
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=512)
+    g = synth.gbuffer_iid(w, h, 3)
+    # HZB: with even dims all the way down to mip 3, every mip is the 2x2 min-pool of its parent
+    lay = HzbLayout(w, h)
+    d_depth = to_device(g.depth)
+    hzb = torch.zeros(lay.total, device="cuda")
+    hotpath.build_hzb(d_depth, hzb, lay)
+    parent = d_depth.view(1, 1, h, w)
+    for (off, mw, mh) in lay.as_list()[:4]:
+        pooled = -F.max_pool2d(-parent, 2)
+        mip = hzb[off:off + mw * mh].view(1, 1, mh, mw)
+        assert torch.equal(pooled, mip)
+        parent = mip
+    # the top of the chain is the global minimum
+    off, mw, mh = lay.as_list()[-1]
+    assert (mw, mh) == (1, 1)
+    # odd-sized parents drop their last row/column (floor), so the 1x1 mip is >= the true minimum
+    assert float(hzb[off]) >= float(d_depth.min())
+    # oracle agrees on a cropped corner that includes the clamped edge
+    ref = oracle.build_hzb(g.depth, lay.as_list(), lay.total)
+    assert np.array_equal(hzb.cpu().numpy().view(np.uint32)[lay.mips[4].offset:], np.nan_to_num(ref, nan=0.0).view(np.uint32)[lay.mips[4].offset:])
+
+    # lighting: 8 row bands == whole frame, and the per-band result does not depend on the band it was computed in
+    shadow = synth.shadow_map_noise(512, 1)
+    env = synth.env_cube_procedural(64, 7)
+    lut = synth.brdf_lut_procedural(128, 32)
+    fc.scene.EnvMapMipCount = 7.0
+    tables = hotpath.make_tables(to_device(shadow), hotpath.stage_env_cube(env, 64, 7), 64, 7, to_device(lut))
+    dA, dB, dC = to_device(g.A), to_device(g.B), to_device(g.C)
+    whole = to_device(g.hdr)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, d_depth, tables, whole, w, h)
+    parts = to_device(g.hdr)
+    for r in range(8):
+        sl = slice(r * 270, (r + 1) * 270)
+        hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA[sl], dB[sl], dC[sl], d_depth[sl], tables, parts[sl], w, h, r * 270, 270)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, parts)
+    out = whole.cpu().numpy().view(np.float16).astype(np.float32)
+    assert np.isfinite(out).all(), "after the sky pass no pixel may be NaN/inf"
+    assert (out[..., 3][g.depth == 0] == 1.0).all() and (out[..., 3][g.depth > 0] == 2.0).all()
+    # oracle on a 64-row band of the 4K frame
+    r0 = 1024
+    sl = slice(r0, r0 + 64)
+    ref_l, frag = oracle.deferred_lighting(fc.scene, g.A[sl], g.B[sl], g.C[sl], shadow, env, 64, 7, lut, g.hdr[sl], w, h, r0, 64, want_fragile=True)
+    ref = oracle.sky_atmosphere(fc.sky, g.depth[sl], ref_l, w, h, r0, 64)
+    nbad, worst, _ = hdr_mismatch(whole[sl].cpu().numpy().view(np.uint16), ref, exclude=frag)
+    assert nbad == 0, (nbad, worst)
+
+
+def test_cull_one_million(hotpath, oracle):
+    """BASELINE config 5 (scaled HZB): 1 M instances, bit-exact words + list against the oracle."""
+    cnt, stats = _cull_case(hotpath, oracle, 1_000_000, True, seed=5, w=960, h=540, box=400.0)
+    assert cnt > 1000 and stats[0] > 0 and stats[1] > 0

@@ -1,0 +1,248 @@
+// CullIndirectArgs for gfx950 — frustum + HZB occlusion cull of instance AABBs, plus the visible-list compaction the
+// reference does not have.
+//
+// Reference: Shaders/CullIndirectArgs.hlsl:24-167 ([numthreads(64,1,1)], one thread per instance, writes the
+// InstanceCount word at byte 44 of each 64-byte FIndirectDrawCommand), dispatched by FRenderer::DispatchGpuCulling
+// (Source/Render/Renderer.cpp:394-472). The arithmetic below follows the HLSL statement by statement and this file is
+// built with -ffp-contract=off and IEEE division so every intermediate equals the oracle's; floor(log2(x)) is taken from
+// the IEEE exponent.
+//
+// MI355X shape: 256-thread workgroups (4 x wave64). The workgroup's 256 AABBs (8 KB) are staged through LDS with
+// fully-coalesced 16-byte loads, then each lane reads its own min/max pair. Visibility is a wave ballot: lane 0 keeps
+// the 64-bit mask, popcounts give per-wave and per-workgroup counts. Compaction is deterministic (ascending index, no
+// atomic append): pass 1 stores per-wave masks and per-workgroup counts, pass 2 takes the exclusive prefix of the
+// workgroup counts and scatters index = base + mbcnt(mask). Up to 256 instances (Sponza 25, pica_pica 170) both passes
+// run inside one launch.
+
+#include "ur_internal.h"
+
+#include <cstring>
+
+namespace {
+
+struct CullParams {
+    // CullingConstants, CullIndirectArgs.hlsl:1-11
+    float4 FrustumPlanes[6];
+    float ViewProjection[16];
+    uint32_t ModelCount, HZBEnabled, HZBMipCount, HZBWidth, HZBHeight, DebugPrintEnabled;
+    const float4* bounds;
+    const float* hzb;
+    uint8_t* args;
+    uint32_t* stats;
+    uint32_t* visible_idx;
+    uint32_t* visible_count;
+    uint32_t* block_counts;
+    uint64_t* wave_masks;
+    uint32_t index_base;
+    uint32_t mip_offset[UR_MAX_HZB_MIPS];
+    uint32_t mip_width[UR_MAX_HZB_MIPS];
+};
+
+__device__ __forceinline__ float saturate_f(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) { return (ax * bx + ay * by) + az * bz; }
+
+__device__ __forceinline__ bool IsAabbVisible(const CullParams& C, float3 mn, float3 mx)
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float4 plane = C.FrustumPlanes[i];
+        const float px = plane.x >= 0.0f ? mx.x : mn.x;
+        const float py = plane.y >= 0.0f ? mx.y : mn.y;
+        const float pz = plane.z >= 0.0f ? mx.z : mn.z;
+        if (dot3(plane.x, plane.y, plane.z, px, py, pz) + plane.w < 0.0f) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool IsOccluded(const CullParams& C, float3 mn, float3 mx)
+{
+    if (C.HZBEnabled == 0 || C.HZBWidth == 0 || C.HZBHeight == 0 || C.HZBMipCount == 0) return false;
+    const float* M = C.ViewProjection;
+    float minUx = 1.0f, minUy = 1.0f, maxUx = 0.0f, maxUy = 0.0f, maxDepth = 0.0f;
+    bool anyBehind = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float cx = (i & 1) ? mx.x : mn.x, cy = (i & 2) ? mx.y : mn.y, cz = (i & 4) ? mx.z : mn.z;
+        const float clx = ((cx * M[0] + cy * M[4]) + cz * M[8]) + 1.0f * M[12];
+        const float cly = ((cx * M[1] + cy * M[5]) + cz * M[9]) + 1.0f * M[13];
+        const float clz = ((cx * M[2] + cy * M[6]) + cz * M[10]) + 1.0f * M[14];
+        const float clw = ((cx * M[3] + cy * M[7]) + cz * M[11]) + 1.0f * M[15];
+        if (clw <= 0.0f) anyBehind = true; // the HLSL breaks out here; nothing after the break feeds the result
+        const float nx = clx / clw, ny = cly / clw, nz = clz / clw;
+        const float ux = nx * 0.5f + 0.5f;
+        const float uy = 1 - (ny * 0.5f + 0.5f);
+        minUx = fminf(minUx, ux); minUy = fminf(minUy, uy);
+        maxUx = fmaxf(maxUx, ux); maxUy = fmaxf(maxUy, uy);
+        maxDepth = fmaxf(maxDepth, nz);
+    }
+    if (anyBehind) return false;
+    if (maxUx < 0.0f || maxUy < 0.0f || minUx > 1.0f || minUy > 1.0f) return false;
+    minUx = saturate_f(minUx); minUy = saturate_f(minUy);
+    maxUx = saturate_f(maxUx); maxUy = saturate_f(maxUy);
+    const float ex = maxUx - minUx, ey = maxUy - minUy;
+    const float psx = ex * (float)C.HZBWidth, psy = ey * (float)C.HZBHeight;
+    const float maxDim = fmaxf(psx, psy);
+    uint32_t mipLevel = 0;
+    if (maxDim > 1.0f) {
+        const uint32_t e = ((__float_as_uint(maxDim) >> 23) & 0xFFu) - 127u; // floor(log2(maxDim)), exact
+        const float l = fminf(fmaxf((float)e, 0.0f), (float)(C.HZBMipCount - 1u));
+        mipLevel = (uint32_t)l;
+    }
+    const uint32_t mipWidth = max(1u, C.HZBWidth >> mipLevel);
+    const uint32_t mipHeight = max(1u, C.HZBHeight >> mipLevel);
+    uint32_t minX = (uint32_t)(minUx * (float)mipWidth), minY = (uint32_t)(minUy * (float)mipHeight);
+    uint32_t maxX = (uint32_t)(maxUx * (float)mipWidth), maxY = (uint32_t)(maxUy * (float)mipHeight);
+    minX = min(minX, mipWidth - 1u); minY = min(minY, mipHeight - 1u);
+    maxX = min(maxX, mipWidth - 1u); maxY = min(maxY, mipHeight - 1u);
+    const float* mip = C.hzb + C.mip_offset[mipLevel];
+    const uint32_t pitch = C.mip_width[mipLevel];
+    float hzbDepth = 1.0f;
+    hzbDepth = fminf(hzbDepth, mip[(size_t)minY * pitch + minX]);
+    hzbDepth = fminf(hzbDepth, mip[(size_t)minY * pitch + maxX]);
+    hzbDepth = fminf(hzbDepth, mip[(size_t)maxY * pitch + minX]);
+    hzbDepth = fminf(hzbDepth, mip[(size_t)maxY * pitch + maxX]);
+    return maxDepth < hzbDepth;
+}
+
+// Scatter the visible indices of one 256-instance block. masks[w] = ballot of wave w; base = visible before this block.
+__device__ __forceinline__ void ScatterBlock(const CullParams& C, uint32_t block, const uint64_t* masks, uint32_t base)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t wave_base = base;
+    for (uint32_t w = 0; w < wave; ++w) wave_base += __popcll(masks[w]);
+    const uint64_t m = masks[wave];
+    if ((m >> lane) & 1ull) {
+        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+        C.visible_idx[wave_base + rank] = block * 256u + threadIdx.x + C.index_base;
+    }
+}
+
+template <bool SINGLE_BLOCK>
+__global__ __launch_bounds__(256) void cull_kernel(CullParams C)
+{
+    __shared__ float4 sb[512];
+    __shared__ uint64_t smask[4];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t first = blockIdx.x * 256u;
+    const uint32_t index = first + tid;
+
+    // stage this block's AABBs: 512 float4, lane-consecutive 16-byte loads
+    const uint32_t nb = min(512u, (C.ModelCount - first) * 2u);
+    const float4* src = C.bounds + (size_t)first * 2u;
+    if (tid < nb) sb[tid] = src[tid];
+    if (tid + 256u < nb) sb[tid + 256u] = src[tid + 256u];
+    __syncthreads();
+
+    bool visible = false, frustumVisible = true, occluded = false;
+    const bool active = index < C.ModelCount;
+    if (active) {
+        const float4 bmin = sb[2u * tid], bmax = sb[2u * tid + 1u];
+        const float3 mn = make_float3(bmin.x, bmin.y, bmin.z), mx = make_float3(bmax.x, bmax.y, bmax.z);
+        frustumVisible = IsAabbVisible(C, mn, mx);
+        visible = frustumVisible;
+        if (visible && C.HZBEnabled != 0) {
+            occluded = IsOccluded(C, mn, mx);
+            visible = !occluded;
+        }
+        *reinterpret_cast<uint32_t*>(C.args + (size_t)index * UR_INDIRECT_COMMAND_STRIDE + UR_INDIRECT_INSTANCE_COUNT_OFFSET) = visible ? 1u : 0u;
+    }
+
+    if (C.DebugPrintEnabled != 0 && C.stats != nullptr) { // one atomic per wave instead of one per lane
+        const uint32_t nf = __popcll(__ballot(active && !frustumVisible));
+        const uint32_t no = __popcll(__ballot(active && frustumVisible && occluded));
+        if (lane == 0) {
+            if (nf) atomicAdd(&C.stats[0], nf);
+            if (no) atomicAdd(&C.stats[1], no);
+        }
+    }
+
+    if (C.visible_idx == nullptr) return; // uniform
+    const uint64_t mask = __ballot(visible);
+    if (lane == 0) smask[wave] = mask;
+    __syncthreads();
+    if (SINGLE_BLOCK) {
+        ScatterBlock(C, 0, smask, 0);
+        if (tid == 0) *C.visible_count = __popcll(smask[0]) + __popcll(smask[1]) + __popcll(smask[2]) + __popcll(smask[3]);
+    } else {
+        if (lane == 0) C.wave_masks[(size_t)blockIdx.x * 4u + wave] = mask;
+        if (tid == 0) C.block_counts[blockIdx.x] = __popcll(smask[0]) + __popcll(smask[1]) + __popcll(smask[2]) + __popcll(smask[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(CullParams C, uint32_t num_blocks)
+{
+    __shared__ uint32_t spart[4];
+    __shared__ uint64_t smask[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // exclusive prefix of the block counts in front of this block
+    uint32_t s = 0;
+    for (uint32_t b = tid; b < blockIdx.x; b += 256u) s += C.block_counts[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) spart[wave] = s;
+    if (tid < 4) smask[tid] = C.wave_masks[(size_t)blockIdx.x * 4u + tid];
+    __syncthreads();
+    const uint32_t base = spart[0] + spart[1] + spart[2] + spart[3];
+    ScatterBlock(C, blockIdx.x, smask, base);
+    if (blockIdx.x == num_blocks - 1u && tid == 0)
+        *C.visible_count = base + __popcll(smask[0]) + __popcll(smask[1]) + __popcll(smask[2]) + __popcll(smask[3]);
+}
+
+__global__ void zero_count_kernel(uint32_t* p) { *p = 0; }
+
+} // namespace
+
+namespace ur {
+
+int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb, const ur_mip_desc* mips,
+                void* indirect_args, uint32_t* stats2, uint32_t* visible_idx, uint32_t* visible_count, uint32_t index_base)
+{
+    CullParams P{};
+    static_assert(sizeof(float4) * 6 + sizeof(float) * 16 + 6 * 4 == UR_CULL_CONSTANT_DWORDS * 4, "46 dwords");
+    std::memcpy(&P, constants, UR_CULL_CONSTANT_DWORDS * 4);
+    P.bounds = reinterpret_cast<const float4*>(bounds);
+    P.hzb = hzb;
+    P.args = static_cast<uint8_t*>(indirect_args);
+    P.stats = stats2;
+    P.visible_idx = visible_idx;
+    P.visible_count = visible_count;
+    P.index_base = index_base;
+    if (P.HZBEnabled != 0) {
+        for (uint32_t m = 0; m < P.HZBMipCount && m < UR_MAX_HZB_MIPS; ++m) {
+            P.mip_offset[m] = mips[m].offset;
+            P.mip_width[m] = mips[m].width;
+        }
+    }
+    const uint32_t n = P.ModelCount;
+    if (n == 0) {
+        if (visible_count) {
+            hipLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, ctx->stream, visible_count);
+            UR_HIP_TRY(hipGetLastError());
+        }
+        return UR_OK;
+    }
+    const uint32_t blocks = (n + 255u) / 256u;
+    if (blocks == 1) {
+        hipLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, P);
+        UR_HIP_TRY(hipGetLastError());
+        return UR_OK;
+    }
+    if (visible_idx) {
+        if (n > ctx->ws_instances) {
+            const int rc = ur_reserve(ctx, n);
+            if (rc != UR_OK) return rc;
+        }
+        P.block_counts = ctx->block_counts;
+        P.wave_masks = ctx->wave_masks;
+    }
+    hipLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    UR_HIP_TRY(hipGetLastError());
+    if (visible_idx) {
+        hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P, blocks);
+        UR_HIP_TRY(hipGetLastError());
+    }
+    return UR_OK;
+}
+
+} // namespace ur

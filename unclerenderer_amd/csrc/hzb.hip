@@ -1,0 +1,154 @@
+// BuildHZB for gfx950 — min-depth mip chain (reverse-Z: min == farthest).
+//
+// Reference: Shaders/BuildHZB.hlsl:34-126 (8x8 groups, <=4 mips per dispatch through groupshared tiles) and the
+// dispatch loop Source/Render/DeferredRenderer.cpp:1046-1207. The values produced here are bit-identical to that
+// chain, including its out-of-range fills (1.0 below the first mip of a dispatch, 0.0 below the second and third —
+// BuildHZB.hlsl:47,81,104). What is NOT kept is the reference's launch shape: one workgroup here is
+// four wave64s covering a 128x32 source tile; each lane owns a 4x4 source block in registers (four 16-byte loads,
+// 512 contiguous bytes per wave row), so mips k and k+1 never touch LDS, mip k+2 is two DPP/shuffle steps inside the
+// wave (lane^1, lane^32) and only mip k+3 crosses waves through a 64-float LDS tile. One barrier per workgroup instead
+// of three; HBM traffic == algorithmic bytes (every source texel read once, every mip texel written once).
+//
+// Built with -ffp-contract=off; the only arithmetic is fminf.
+
+#include "ur_internal.h"
+
+namespace {
+
+struct HzbDispatch {
+    const float* src;
+    float* dst[4];
+    uint32_t SW, SH;
+    uint32_t W[4], H[4];
+    uint32_t mips;
+    uint32_t vec4_ok; // SW % 4 == 0 and src 16-byte aligned
+    uint32_t pair_ok; // W[0] even and dst[0] 8-byte aligned
+};
+
+__device__ __forceinline__ float min4(float a, float b, float c, float d) { return fminf(fminf(a, b), fminf(c, d)); }
+
+__global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
+{
+    __shared__ float sh2[4][16];
+
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
+    const uint32_t x1 = blockIdx.x * 32u + tx, y1 = blockIdx.y * 8u + ty; // coords in mip k+1 (== 4x4 source block index)
+    const uint32_t sx = x1 * 4u, sy = y1 * 4u;
+
+    // ---- mip k: four texels (2x1+i, 2y1+j) from the 4x4 source block, clamped reads (SampleDepth, :34-39)
+    float v0[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}}; // out-of-range lanes hold 1.0 (:47)
+    const bool any0 = (x1 * 2u < p.W[0]) && (y1 * 2u < p.H[0]);
+    if (any0) {
+        float s[4][4];
+        if (p.vec4_ok && sx + 3u < p.SW && sy + 3u < p.SH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 q = *reinterpret_cast<const float4*>(p.src + (size_t)(sy + r) * p.SW + sx);
+                s[r][0] = q.x; s[r][1] = q.y; s[r][2] = q.z; s[r][3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t yy = min(sy + r, p.SH - 1u);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[r][c] = p.src[(size_t)yy * p.SW + min(sx + c, p.SW - 1u)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t x0 = x1 * 2u + i, y0 = y1 * 2u + j;
+                if (x0 < p.W[0] && y0 < p.H[0]) v0[j][i] = min4(s[2 * j][2 * i], s[2 * j][2 * i + 1], s[2 * j + 1][2 * i], s[2 * j + 1][2 * i + 1]);
+            }
+        float* d0 = p.dst[0];
+        const uint32_t x0 = x1 * 2u, y0 = y1 * 2u;
+        if (p.pair_ok && x0 + 1u < p.W[0]) { // 8-byte aligned pair
+            *reinterpret_cast<float2*>(d0 + (size_t)y0 * p.W[0] + x0) = make_float2(v0[0][0], v0[0][1]);
+            if (y0 + 1u < p.H[0]) *reinterpret_cast<float2*>(d0 + (size_t)(y0 + 1u) * p.W[0] + x0) = make_float2(v0[1][0], v0[1][1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (x0 + i < p.W[0] && y0 + j < p.H[0]) d0[(size_t)(y0 + j) * p.W[0] + x0 + i] = v0[j][i];
+        }
+    }
+    if (p.mips < 2u) return;
+
+    // ---- mip k+1: this lane's texel; out-of-range lanes hold 0.0 (:81)
+    float v1 = 0.0f;
+    if (x1 < p.W[1] && y1 < p.H[1]) {
+        v1 = min4(v0[0][0], v0[0][1], v0[1][0], v0[1][1]);
+        p.dst[1][(size_t)y1 * p.W[1] + x1] = v1;
+    }
+    if (p.mips < 3u) return; // uniform
+
+    // ---- mip k+2: 2x2 of v1 lives in lanes {l, l^1, l^32, l^33} of this wave (wave = rows 2w, 2w+1 of the tile)
+    float m = fminf(v1, __shfl_xor(v1, 1));
+    m = fminf(m, __shfl_xor(m, 32));
+    const uint32_t x2 = x1 >> 1, y2 = y1 >> 1;
+    float v2 = 0.0f; // out-of-range holds 0.0 (:104)
+    if (x2 < p.W[2] && y2 < p.H[2]) v2 = m;
+    if (((tx | ty) & 1u) == 0u) {
+        if (x2 < p.W[2] && y2 < p.H[2]) p.dst[2][(size_t)y2 * p.W[2] + x2] = v2;
+        sh2[ty >> 1][tx >> 1] = v2;
+    }
+    if (p.mips < 4u) return; // uniform
+    __syncthreads();
+
+    // ---- mip k+3: 2x2 of v2 through LDS
+    if (((tx | ty) & 3u) == 0u) {
+        const uint32_t x3 = x1 >> 2, y3 = y1 >> 2;
+        if (x3 < p.W[3] && y3 < p.H[3]) {
+            const uint32_t cx = tx >> 1, cy = ty >> 1;
+            p.dst[3][(size_t)y3 * p.W[3] + x3] = min4(sh2[cy][cx], sh2[cy][cx + 1], sh2[cy + 1][cx], sh2[cy + 1][cx + 1]);
+        }
+    }
+}
+
+} // namespace
+
+namespace ur {
+
+int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb, const ur_mip_desc* mips,
+                     uint32_t mip_count)
+{
+    // Same grouping as the reference's while-loop (DeferredRenderer.cpp:1046-1207): <=4 mips per launch, first launch
+    // reads the depth buffer with clamped 2x2 footprints, later launches read the last mip of the previous launch.
+    uint32_t mip = 0;
+    while (mip < mip_count) {
+        const uint32_t n = (mip_count - mip) < 4u ? (mip_count - mip) : 4u;
+        HzbDispatch d{};
+        if (mip == 0) {
+            d.src = depth;
+            d.SW = src_w;
+            d.SH = src_h;
+        } else {
+            d.src = hzb + mips[mip - 1].offset;
+            d.SW = mips[mip - 1].width;
+            d.SH = mips[mip - 1].height;
+        }
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (k < n) {
+                d.dst[k] = hzb + mips[mip + k].offset;
+                d.W[k] = mips[mip + k].width;
+                d.H[k] = mips[mip + k].height;
+            } else {
+                d.dst[k] = nullptr;
+                d.W[k] = 0;
+                d.H[k] = 0;
+            }
+        }
+        d.mips = n;
+        d.vec4_ok = ((d.SW & 3u) == 0u && (reinterpret_cast<uintptr_t>(d.src) & 15u) == 0u) ? 1u : 0u;
+        d.pair_ok = ((d.W[0] & 1u) == 0u && (reinterpret_cast<uintptr_t>(d.dst[0]) & 7u) == 0u) ? 1u : 0u;
+        const dim3 grid((d.W[0] + 63u) / 64u, (d.H[0] + 15u) / 16u);
+        hipLaunchKernelGGL(hzb_reduce4_kernel, grid, dim3(256), 0, ctx->stream, d);
+        UR_HIP_TRY(hipGetLastError());
+        mip += n;
+    }
+    return UR_OK;
+}
+
+} // namespace ur

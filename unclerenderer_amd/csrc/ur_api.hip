@@ -1,0 +1,300 @@
+// C-ABI of include/ur_hotpath.h: argument validation, context/workspace management, setup-time staging.
+// The kernels live in hzb.hip, cull.hip and lighting.hip.
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+#include "ur_internal.h"
+
+namespace ur {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+} // namespace ur
+
+using ur::set_error;
+
+namespace {
+
+// ---- bordered cube staging (host) ------------------------------------------------------------------------------------
+// Face addressing is D3D's (+X,-X,+Y,-Y,+Z,-Z; ties z > y > x). A border texel is the texel of the adjacent face that the
+// one-texel overshoot lands on when the face plane is folded over the shared edge; a corner border texel first clamps its
+// second coordinate into the face (same rule as the oracle's FetchCubeTexel — the rule is the specification).
+struct FaceAxes { int major, su, sv; double ms, us, vs; }; // p[major]=ms, p[su]=us*s, p[sv]=vs*t
+const FaceAxes kFaces[6] = {
+    {0, 2, 1, +1, -1, -1}, // +X: (1, -t, -s)
+    {0, 2, 1, -1, +1, -1}, // -X: (-1, -t, s)
+    {1, 0, 2, +1, +1, +1}, // +Y: (s, 1, t)
+    {1, 0, 2, -1, +1, -1}, // -Y: (s, -1, -t)
+    {2, 0, 1, +1, +1, -1}, // +Z: (s, -t, 1)
+    {2, 0, 1, -1, -1, -1}, // -Z: (-s, -t, -1)
+};
+
+void resolve_border(int N, int face, int i, int j, int& oface, int& oi, int& oj)
+{
+    const bool iOut = i < 0 || i >= N, jOut = j < 0 || j >= N;
+    if (!iOut && !jOut) { oface = face; oi = i; oj = j; return; }
+    if (iOut && jOut) j = j < 0 ? 0 : N - 1;
+    const double s = 2.0 * (i + 0.5) / N - 1.0, t = 2.0 * (j + 0.5) / N - 1.0;
+    const FaceAxes& F = kFaces[face];
+    double p[3];
+    p[F.major] = F.ms; p[F.su] = F.us * s; p[F.sv] = F.vs * t;
+    const double over = (iOut ? std::fabs(s) : std::fabs(t)) - 1.0;
+    p[F.major] *= (1.0 - over);
+    const int oa = iOut ? F.su : F.sv;
+    p[oa] = p[oa] > 0 ? 1.0 : -1.0;
+    // the folded point lies on the face whose axis is `oa`
+    const int nf = oa * 2 + (p[oa] > 0 ? 0 : 1);
+    const FaceAxes& G = kFaces[nf];
+    const double ns = p[G.su] / G.us, nt = p[G.sv] / G.vs;
+    oface = nf;
+    oi = (int)std::floor((ns + 1.0) * 0.5 * N);
+    oj = (int)std::floor((nt + 1.0) * 0.5 * N);
+    oi = oi < 0 ? 0 : (oi >= N ? N - 1 : oi);
+    oj = oj < 0 ? 0 : (oj >= N ? N - 1 : oj);
+}
+
+bool valid_hzb_chain(uint32_t src_w, uint32_t src_h, const ur_mip_desc* mips, uint32_t mip_count)
+{
+    if (!mips || mip_count == 0 || mip_count > UR_MAX_HZB_MIPS) return false;
+    uint32_t w = (src_w + 1) / 2, h = (src_h + 1) / 2;
+    w = w ? w : 1; h = h ? h : 1;
+    for (uint32_t m = 0; m < mip_count; ++m) {
+        if (mips[m].width != w || mips[m].height != h) return false;
+        w = w / 2 ? w / 2 : 1; h = h / 2 ? h / 2 : 1;
+    }
+    return true;
+}
+
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+
+} // namespace
+
+extern "C" {
+
+const char* ur_last_error(void) { return ur::g_error; }
+const char* ur_version(void) { return "unclerenderer_amd hotpath 0.1 (gfx950)"; }
+
+ur_ctx* ur_create(int device, void* stream)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        set_error("ur_create: no HIP device %d (count %d)", device, count);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        set_error("ur_create: hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    ur_ctx* ctx = new ur_ctx();
+    ctx->device = device;
+    ctx->stream = static_cast<hipStream_t>(stream);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // sRGB8 -> linear (exact IEC 61966-2-1 curve, evaluated in double)
+    float table[256];
+    for (int i = 0; i < 256; ++i) {
+        const double c = i / 255.0;
+        table[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+    }
+    if (hipMalloc(&ctx->srgb_table, sizeof(table)) != hipSuccess ||
+        hipMemcpy(ctx->srgb_table, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("ur_create: sRGB table upload failed");
+        ur_destroy(ctx);
+        return nullptr;
+    }
+    if (ur_reserve(ctx, 1u << 20) != UR_OK) {
+        ur_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+void ur_destroy(ur_ctx* ctx)
+{
+    if (!ctx) return;
+    if (ctx->srgb_table) (void)hipFree(ctx->srgb_table);
+    if (ctx->block_counts) (void)hipFree(ctx->block_counts);
+    if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
+    delete ctx;
+}
+
+int ur_reserve(ur_ctx* ctx, uint32_t max_instances)
+{
+    if (!ctx) return UR_EINVAL;
+    if (max_instances <= ctx->ws_instances) return UR_OK;
+    UR_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->block_counts) (void)hipFree(ctx->block_counts);
+    if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
+    ctx->block_counts = nullptr; ctx->wave_masks = nullptr; ctx->ws_instances = 0;
+    const size_t blocks = ((size_t)max_instances + 255u) / 256u;
+    if (hipMalloc(&ctx->block_counts, blocks * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&ctx->wave_masks, blocks * 4u * sizeof(uint64_t)) != hipSuccess) {
+        set_error("ur_reserve: workspace allocation for %u instances failed", max_instances);
+        return UR_ENOMEM;
+    }
+    ctx->ws_instances = (uint32_t)(blocks * 256u);
+    return UR_OK;
+}
+
+uint32_t ur_hzb_layout(uint32_t src_w, uint32_t src_h, ur_mip_desc* mips, uint32_t* mip_count)
+{
+    if (!mips || !mip_count || src_w == 0 || src_h == 0) return 0;
+    uint32_t w = (src_w + 1) / 2, h = (src_h + 1) / 2;
+    w = w ? w : 1; h = h ? h : 1;
+    uint32_t n = 0, off = 0;
+    for (;;) {
+        if (n >= UR_MAX_HZB_MIPS) return 0;
+        mips[n].offset = off; mips[n].width = w; mips[n].height = h;
+        ++n;
+        off += (w * h + 63u) & ~63u; // every mip starts on a 256-byte boundary
+        if (!(w > 1 || h > 1)) break;
+        w = w / 2 ? w / 2 : 1; h = h / 2 ? h / 2 : 1;
+    }
+    *mip_count = n;
+    return off;
+}
+
+int ur_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base, const ur_mip_desc* mips,
+                 uint32_t mip_count)
+{
+    if (!ctx || !depth || !hzb_base || src_w == 0 || src_h == 0) { set_error("ur_build_hzb: null/zero argument"); return UR_EINVAL; }
+    if (!valid_hzb_chain(src_w, src_h, mips, mip_count)) { set_error("ur_build_hzb: mip chain does not match CreateHZBResources sizing"); return UR_EINVAL; }
+    return ur::launch_build_hzb(ctx, depth, src_w, src_h, hzb_base, mips, mip_count);
+}
+
+int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,
+                             const ur_mip_desc* mips, void* indirect_args, uint32_t* stats2, uint32_t* visible_idx,
+                             uint32_t* visible_count, uint32_t index_base)
+{
+    if (!ctx || !constants) { set_error("ur_cull_indirect_args: null ctx/constants"); return UR_EINVAL; }
+    const uint32_t n = constants[40], hzb_on = constants[41], mipc = constants[42];
+    if ((visible_idx == nullptr) != (visible_count == nullptr)) { set_error("ur_cull_indirect_args: visible_idx and visible_count go together"); return UR_EINVAL; }
+    if (n != 0 && (!bounds || !indirect_args)) { set_error("ur_cull_indirect_args: null bounds/indirect_args"); return UR_EINVAL; }
+    if (n != 0 && hzb_on != 0 && constants[43] != 0 && constants[44] != 0 && mipc != 0) {
+        if (!hzb_base || !mips || mipc > UR_MAX_HZB_MIPS) { set_error("ur_cull_indirect_args: HZB enabled but hzb/mips missing"); return UR_EINVAL; }
+        if (mips[0].width != constants[43] || mips[0].height != constants[44]) { set_error("ur_cull_indirect_args: HZBWidth/Height do not match mips[0]"); return UR_EINVAL; }
+    }
+    return ur::launch_cull(ctx, constants, bounds, hzb_base, mips, indirect_args, stats2, visible_idx, visible_count, index_base);
+}
+
+int ur_cull_indirect_args(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,
+                          const ur_mip_desc* mips, void* indirect_args, uint32_t* stats2, uint32_t* visible_idx,
+                          uint32_t* visible_count)
+{
+    return ur_cull_indirect_args_ex(ctx, constants, bounds, hzb_base, mips, indirect_args, stats2, visible_idx, visible_count, 0);
+}
+
+size_t ur_env_cube_texels(uint32_t base_size, uint32_t mip_count)
+{
+    if (base_size == 0 || mip_count == 0 || mip_count > 16) return 0;
+    size_t n = 0;
+    for (uint32_t m = 0; m < mip_count; ++m) {
+        const size_t e = (base_size >> m > 1u ? base_size >> m : 1u) + 2u;
+        n += 6u * e * e;
+    }
+    return n;
+}
+
+int ur_stage_env_cube(ur_ctx* ctx, const ur_half4* src, uint32_t base, uint32_t mip_count, ur_half4* dst_device)
+{
+    if (!ctx || !src || !dst_device || ur_env_cube_texels(base, mip_count) == 0) { set_error("ur_stage_env_cube: bad argument"); return UR_EINVAL; }
+    std::vector<size_t> mip_off(mip_count);
+    size_t face_stride = 0;
+    for (uint32_t m = 0; m < mip_count; ++m) {
+        mip_off[m] = face_stride;
+        const size_t n = base >> m > 1u ? base >> m : 1u;
+        face_stride += n * n;
+    }
+    std::vector<ur_half4> out(ur_env_cube_texels(base, mip_count));
+    size_t off = 0;
+    for (uint32_t m = 0; m < mip_count; ++m) {
+        const int N = (int)(base >> m > 1u ? base >> m : 1u), E = N + 2;
+        for (int f = 0; f < 6; ++f)
+            for (int j = -1; j <= N; ++j)
+                for (int i = -1; i <= N; ++i) {
+                    int sf, si, sj;
+                    resolve_border(N, f, i, j, sf, si, sj);
+                    out[off + ((size_t)f * E + (j + 1)) * E + (i + 1)] = src[(size_t)sf * face_stride + mip_off[m] + (size_t)sj * N + si];
+                }
+        off += (size_t)6 * E * E;
+    }
+    UR_HIP_TRY(hipMemcpy(dst_device, out.data(), out.size() * sizeof(ur_half4), hipMemcpyHostToDevice));
+    return UR_OK;
+}
+
+static int check_band(const char* who, ur_ctx* ctx, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows)
+{
+    if (!ctx || w == 0 || h == 0 || (uint64_t)row0 + rows > h) {
+        set_error("%s: bad frame/band (w=%u h=%u row0=%u rows=%u)", who, w, h, row0, rows);
+        return UR_EINVAL;
+    }
+    return UR_OK;
+}
+
+int ur_deferred_lighting(ur_ctx* ctx, const ur_scene_constants* scene, const ur_half4* a, const ur_half4* b, const uint32_t* c,
+                         const ur_lighting_tables* tables, ur_half4* hdr, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows)
+{
+    const int rc = check_band("ur_deferred_lighting", ctx, w, h, row0, rows);
+    if (rc != UR_OK) return rc;
+    if (!scene || !a || !b || !c || !tables || !hdr) { set_error("ur_deferred_lighting: null argument"); return UR_EINVAL; }
+    return ur::launch_lighting(ctx, scene, nullptr, a, b, c, nullptr, tables, hdr, w, h, row0, rows, ur::UR_MODE_LIGHTING);
+}
+
+int ur_sky_atmosphere(ur_ctx* ctx, const ur_sky_constants* sky, const float* depth, ur_half4* hdr, uint32_t w, uint32_t h,
+                      uint32_t row0, uint32_t rows)
+{
+    const int rc = check_band("ur_sky_atmosphere", ctx, w, h, row0, rows);
+    if (rc != UR_OK) return rc;
+    if (!sky || !depth || !hdr) { set_error("ur_sky_atmosphere: null argument"); return UR_EINVAL; }
+    return ur::launch_lighting(ctx, nullptr, sky, nullptr, nullptr, nullptr, depth, nullptr, hdr, w, h, row0, rows, ur::UR_MODE_SKY);
+}
+
+int ur_deferred_lighting_sky(ur_ctx* ctx, const ur_scene_constants* scene, const ur_sky_constants* sky, const ur_half4* a,
+                             const ur_half4* b, const uint32_t* c, const float* depth, const ur_lighting_tables* tables,
+                             ur_half4* hdr, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows)
+{
+    const int rc = check_band("ur_deferred_lighting_sky", ctx, w, h, row0, rows);
+    if (rc != UR_OK) return rc;
+    if (!scene || !sky || !a || !b || !c || !depth || !tables || !hdr) { set_error("ur_deferred_lighting_sky: null argument"); return UR_EINVAL; }
+    return ur::launch_lighting(ctx, scene, sky, a, b, c, depth, tables, hdr, w, h, row0, rows, ur::UR_MODE_FUSED);
+}
+
+int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, uint32_t h, uint32_t n_ranks, uint32_t rank)
+{
+    if (!ctx || !comm || !hdr_full || n_ranks == 0 || rank >= n_ranks || h % n_ranks != 0) {
+        set_error("ur_allgather_rows: bad argument (h=%u ranks=%u rank=%u)", h, n_ranks, rank);
+        return UR_EINVAL;
+    }
+    // RCCL is resolved at run time from whatever copy the host process already loaded (torch ships its own), so the
+    // library has no link-time dependency on a second RCCL.
+    static nccl_allgather_fn fn = nullptr;
+    if (!fn) {
+        fn = reinterpret_cast<nccl_allgather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
+        if (!fn) {
+            void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) fn = reinterpret_cast<nccl_allgather_fn>(dlsym(lib, "ncclAllGather"));
+        }
+        if (!fn) { set_error("ur_allgather_rows: ncclAllGather not found"); return UR_EUNSUPPORTED; }
+    }
+    const size_t band_bytes = (size_t)w * (h / n_ranks) * sizeof(ur_half4);
+    const char* send = reinterpret_cast<const char*>(hdr_full) + band_bytes * rank;
+    const int rc = fn(send, hdr_full, band_bytes, /*ncclInt8*/ 0, comm, ctx->stream);
+    if (rc != 0) { set_error("ncclAllGather failed (%d)", rc); return UR_EHIP; }
+    return UR_OK;
+}
+
+} // extern "C"

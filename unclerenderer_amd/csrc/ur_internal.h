@@ -1,0 +1,47 @@
+// Internal declarations shared by the C-ABI translation units. Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/ur_hotpath.h"
+
+struct ur_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // compaction workspace (grown by ur_reserve / lazily outside graph capture)
+    uint32_t* block_counts = nullptr; // one per 256-instance block
+    uint64_t* wave_masks = nullptr;   // one per 64 instances
+    uint32_t ws_instances = 0;
+    // sRGB8 -> linear table (256 floats), uploaded once
+    float* srgb_table = nullptr;
+    int cu_count = 256;
+};
+
+namespace ur {
+
+void set_error(const char* fmt, ...);
+
+#define UR_HIP_TRY(expr)                                                                          \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ::ur::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return UR_EHIP;                                                                       \
+        }                                                                                         \
+    } while (0)
+
+// kernels (one file each)
+int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base,
+                     const ur_mip_desc* mips, uint32_t mip_count);
+int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,
+                const ur_mip_desc* mips, void* indirect_args, uint32_t* stats2, uint32_t* visible_idx,
+                uint32_t* visible_count, uint32_t index_base);
+int launch_lighting(ur_ctx* ctx, const ur_scene_constants* scene, const ur_sky_constants* sky, const ur_half4* gbuf_a,
+                    const ur_half4* gbuf_b, const uint32_t* gbuf_c, const float* depth, const ur_lighting_tables* tables,
+                    ur_half4* hdr, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows, int mode);
+enum { UR_MODE_LIGHTING = 0, UR_MODE_SKY = 1, UR_MODE_FUSED = 2 };
+
+} // namespace ur

@@ -1,0 +1,145 @@
+"""Python face of the C-ABI for device tensors (torch is used for device memory and streams only).
+
+Method names follow the reference's passes: CullIndirectArgs (Renderer.cpp:394 DispatchGpuCulling), BuildHZB
+(DeferredRenderer.cpp:998), DeferredLighting (:1219), SkyAtmosphere (:1263).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA/HIP tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+class HzbLayout:
+    def __init__(self, src_w: int, src_h: int):
+        self.src_w, self.src_h = src_w, src_h
+        self.mips = (_lib.MipDesc * _lib.UR_MAX_HZB_MIPS)()
+        n = C.c_uint32(0)
+        self.total = int(_lib.load().ur_hzb_layout(src_w, src_h, self.mips, C.byref(n)))
+        if self.total == 0:
+            raise ValueError(f"bad HZB source size {src_w}x{src_h}")
+        self.count = int(n.value)
+
+    @property
+    def width(self):
+        return self.mips[0].width
+
+    @property
+    def height(self):
+        return self.mips[0].height
+
+    def as_list(self):
+        return [(self.mips[i].offset, self.mips[i].width, self.mips[i].height) for i in range(self.count)]
+
+    def mip_texels(self) -> int:
+        return sum(self.mips[i].width * self.mips[i].height for i in range(self.count))
+
+
+class HotPath:
+    """One ur_ctx bound to a device and a stream."""
+
+    def __init__(self, device: int | None = None, stream: "torch.cuda.Stream | None" = None):
+        self._L = _lib.load()  # raises if the HIP extension is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the hot path has no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else device
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._ctx = self._L.ur_create(self.device, C.c_void_p(self.stream.cuda_stream))
+        if not self._ctx:
+            raise RuntimeError("ur_create failed: " + self._L.ur_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.ur_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def reserve(self, max_instances: int):
+        _lib.check(self._L.ur_reserve(self._ctx, max_instances), "ur_reserve")
+
+    # ---- BuildHZB ----
+    def build_hzb(self, depth: torch.Tensor, hzb: torch.Tensor, layout: HzbLayout):
+        assert depth.dtype == torch.float32 and hzb.dtype == torch.float32 and hzb.numel() >= layout.total
+        assert depth.numel() == layout.src_w * layout.src_h
+        _lib.check(self._L.ur_build_hzb(self._ctx, _ptr(depth), layout.src_w, layout.src_h, _ptr(hzb), layout.mips, layout.count), "ur_build_hzb")
+
+    # ---- CullIndirectArgs ----
+    def cull_indirect_args(self, constants: np.ndarray, bounds: torch.Tensor, hzb, layout, indirect_args: torch.Tensor,
+                           stats=None, visible_idx=None, visible_count=None, index_base: int = 0):
+        constants = np.ascontiguousarray(constants, np.uint32)
+        assert constants.size == _lib.UR_CULL_CONSTANT_DWORDS
+        cptr = constants.ctypes.data_as(C.POINTER(C.c_uint32))
+        mips = layout.mips if layout is not None else None
+        _lib.check(self._L.ur_cull_indirect_args_ex(self._ctx, cptr, _ptr(bounds), _ptr(hzb), mips, _ptr(indirect_args), _ptr(stats),
+                                                    _ptr(visible_idx), _ptr(visible_count), index_base), "ur_cull_indirect_args")
+
+    # ---- lighting tables ----
+    def stage_env_cube(self, cube_dds_order: np.ndarray, base: int, mips: int) -> torch.Tensor:
+        src = np.ascontiguousarray(cube_dds_order, np.uint16)
+        n = int(self._L.ur_env_cube_texels(base, mips))
+        if n == 0:
+            raise ValueError("bad cube size")
+        expect = 6 * sum(max(1, base >> m) ** 2 for m in range(mips))
+        assert src.size == expect * 4, f"cube has {src.size // 4} texels, expected {expect}"
+        dst = torch.empty((n, 4), dtype=torch.int16, device=f"cuda:{self.device}")
+        _lib.check(self._L.ur_stage_env_cube(self._ctx, src.ctypes.data_as(C.c_void_p), base, mips, _ptr(dst)), "ur_stage_env_cube")
+        return dst
+
+    @staticmethod
+    def make_tables(shadow, env_cube, env_base: int, env_mips: int, lut) -> _lib.LightingTables:
+        t = _lib.LightingTables()
+        t.shadow_map = shadow.data_ptr() if shadow is not None else None
+        t.env_cube = env_cube.data_ptr()
+        t.env_base_size, t.env_mip_count = env_base, env_mips
+        t.brdf_lut_rg16 = lut.data_ptr()
+        t.lut_height, t.lut_width = int(lut.shape[0]), int(lut.shape[1])
+        t._keep = (shadow, env_cube, lut)  # keep the tensors alive
+        return t
+
+    # ---- DeferredLighting / SkyAtmosphere ----
+    def deferred_lighting(self, scene, A, B, Cc, tables, hdr, w, h, row0=0, rows=None):
+        rows = h - row0 if rows is None else rows
+        _lib.check(self._L.ur_deferred_lighting(self._ctx, C.byref(scene), _ptr(A), _ptr(B), _ptr(Cc), C.byref(tables), _ptr(hdr), w, h, row0, rows),
+                   "ur_deferred_lighting")
+
+    def sky_atmosphere(self, sky, depth, hdr, w, h, row0=0, rows=None):
+        rows = h - row0 if rows is None else rows
+        _lib.check(self._L.ur_sky_atmosphere(self._ctx, C.byref(sky), _ptr(depth), _ptr(hdr), w, h, row0, rows), "ur_sky_atmosphere")
+
+    def deferred_lighting_sky(self, scene, sky, A, B, Cc, depth, tables, hdr, w, h, row0=0, rows=None):
+        rows = h - row0 if rows is None else rows
+        _lib.check(self._L.ur_deferred_lighting_sky(self._ctx, C.byref(scene), C.byref(sky), _ptr(A), _ptr(B), _ptr(Cc), _ptr(depth), C.byref(tables),
+                                                    _ptr(hdr), w, h, row0, rows), "ur_deferred_lighting_sky")
+
+
+def to_device(a: np.ndarray, device=0) -> torch.Tensor:
+    """numpy -> device tensor, reinterpreting unsigned dtypes torch cannot hold (bit patterns are preserved)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint16:
+        a = a.view(np.int16)
+    elif a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).to(f"cuda:{device}")
+
+
+def to_host(t: torch.Tensor, dtype) -> np.ndarray:
+    return t.detach().cpu().numpy().view(dtype)

@@ -1,0 +1,147 @@
+"""ctypes binding of the C-ABI (include/ur_hotpath.h, include/ur_host.h).
+
+The shared library is the product; there is no Python or CPU fallback. If it is missing, importing the compute
+entry points raises — build it with `python -m unclerenderer_amd.build` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "_build" / "libur_hotpath.so"
+
+UR_OK = 0
+UR_EINVAL, UR_EHIP, UR_ENOMEM, UR_ENODEVICE, UR_EUNSUPPORTED = -1, -2, -3, -4, -5
+UR_MAX_HZB_MIPS = 16
+UR_CULL_CONSTANT_DWORDS = 46
+UR_INDIRECT_COMMAND_STRIDE = 64
+UR_INDIRECT_INSTANCE_COUNT_OFFSET = 44
+
+
+class MipDesc(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class SceneConstants(C.Structure):
+    """FSceneConstants (Source/Render/RendererUtils.h:41-79)."""
+    _fields_ = [
+        ("World", C.c_float * 16), ("View", C.c_float * 16), ("ViewInverse", C.c_float * 16), ("Projection", C.c_float * 16),
+        ("BaseColor", C.c_float * 3), ("LightIntensity", C.c_float),
+        ("LightDirection", C.c_float * 3), ("Padding1", C.c_float),
+        ("CameraPosition", C.c_float * 3), ("Padding2", C.c_float),
+        ("LightColor", C.c_float * 3), ("Padding3", C.c_float),
+        ("EmissiveFactor", C.c_float * 3), ("Padding4", C.c_float),
+        ("LightViewProjection", C.c_float * 16),
+        ("ShadowStrength", C.c_float), ("ShadowBias", C.c_float), ("ShadowMapSize", C.c_float * 2),
+        ("MetallicFactor", C.c_float), ("RoughnessFactor", C.c_float), ("BaseColorAlpha", C.c_float), ("AlphaCutoff", C.c_float),
+        ("AlphaMode", C.c_uint32), ("PaddingMaterial", C.c_uint32 * 3),
+        ("BaseColorTransformOffsetScale", C.c_float * 4), ("BaseColorTransformRotation", C.c_float * 4),
+        ("MetallicRoughnessTransformOffsetScale", C.c_float * 4), ("MetallicRoughnessTransformRotation", C.c_float * 4),
+        ("NormalTransformOffsetScale", C.c_float * 4), ("NormalTransformRotation", C.c_float * 4),
+        ("EmissiveTransformOffsetScale", C.c_float * 4), ("EmissiveTransformRotation", C.c_float * 4),
+        ("EnvMapMipCount", C.c_float), ("PaddingEnvMap", C.c_float * 3),
+        ("ObjectId", C.c_uint32), ("PaddingObjectId", C.c_float * 3),
+    ]
+
+
+class SkyConstants(C.Structure):
+    """FSkyAtmosphereConstants (Source/Render/RendererUtils.h:81-92)."""
+    _fields_ = [
+        ("World", C.c_float * 16), ("View", C.c_float * 16), ("Projection", C.c_float * 16),
+        ("CameraPosition", C.c_float * 3), ("Padding0", C.c_float),
+        ("LightDirection", C.c_float * 3), ("Padding1", C.c_float),
+        ("LightColor", C.c_float * 3), ("Padding2", C.c_float),
+    ]
+
+
+class LightingTables(C.Structure):
+    _fields_ = [
+        ("shadow_map", C.c_void_p), ("env_cube", C.c_void_p), ("env_base_size", C.c_uint32), ("env_mip_count", C.c_uint32),
+        ("brdf_lut_rg16", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
+    ]
+
+
+assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
+
+# name -> (restype, argtypes); every symbol declared in include/*.h
+_VP, _U32, _F = C.c_void_p, C.c_uint32, C.c_float
+_FP = C.POINTER(C.c_float)
+SIGNATURES = {
+    # ur_hotpath.h
+    "ur_create": (_VP, [C.c_int, _VP]),
+    "ur_destroy": (None, [_VP]),
+    "ur_reserve": (C.c_int, [_VP, _U32]),
+    "ur_last_error": (C.c_char_p, []),
+    "ur_version": (C.c_char_p, []),
+    "ur_hzb_layout": (_U32, [_U32, _U32, C.POINTER(MipDesc), C.POINTER(_U32)]),
+    "ur_build_hzb": (C.c_int, [_VP, _VP, _U32, _U32, _VP, C.POINTER(MipDesc), _U32]),
+    "ur_cull_indirect_args": (C.c_int, [_VP, C.POINTER(_U32), _VP, _VP, C.POINTER(MipDesc), _VP, _VP, _VP, _VP]),
+    "ur_cull_indirect_args_ex": (C.c_int, [_VP, C.POINTER(_U32), _VP, _VP, C.POINTER(MipDesc), _VP, _VP, _VP, _VP, _U32]),
+    "ur_env_cube_texels": (C.c_size_t, [_U32, _U32]),
+    "ur_stage_env_cube": (C.c_int, [_VP, _VP, _U32, _U32, _VP]),
+    "ur_deferred_lighting": (C.c_int, [_VP, C.POINTER(SceneConstants), _VP, _VP, _VP, C.POINTER(LightingTables), _VP, _U32, _U32, _U32, _U32]),
+    "ur_sky_atmosphere": (C.c_int, [_VP, C.POINTER(SkyConstants), _VP, _VP, _U32, _U32, _U32, _U32]),
+    "ur_deferred_lighting_sky": (C.c_int, [_VP, C.POINTER(SceneConstants), C.POINTER(SkyConstants), _VP, _VP, _VP, _VP,
+                                           C.POINTER(LightingTables), _VP, _U32, _U32, _U32, _U32]),
+    "ur_allgather_rows": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
+    # ur_host.h
+    "ur_host_look_to_lh": (None, [_FP, _FP, _FP, _FP]),
+    "ur_host_look_at_lh": (None, [_FP, _FP, _FP, _FP]),
+    "ur_host_reverse_z_projection": (None, [_F, _F, _F, _FP]),
+    "ur_host_orthographic_lh": (None, [_F, _F, _F, _F, _FP]),
+    "ur_host_mat_mul": (None, [_FP, _FP, _FP]),
+    "ur_host_mat_inverse": (C.c_int, [_FP, _FP]),
+    "ur_host_frustum_planes": (None, [_FP, _FP]),
+    "ur_host_is_aabb_in_frustum": (C.c_int, [_FP, _FP, _FP]),
+    "ur_host_light_view_projection": (None, [_FP, _F, _FP, _FP]),
+    "ur_host_pack_culling_constants": (None, [_FP, _FP, _U32, _U32, _U32, _U32, _U32, _U32, C.POINTER(_U32)]),
+    "ur_host_fill_scene_constants": (None, [_FP, _FP, _FP, _F, _FP, _FP, _FP, _F, _F, _F, _F, _F, C.POINTER(SceneConstants)]),
+    "ur_host_fill_sky_constants": (None, [_FP, _FP, _FP, _F, _FP, _FP, C.POINTER(SkyConstants)]),
+    "ur_host_direction_from_euler_degrees": (None, [_F, _F, _FP]),
+    "ur_host_camera_forward_from_euler_degrees": (None, [_F, _F, _FP]),
+    "ur_host_light_direction_roundtrip": (None, [_FP, _FP]),
+}
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libur_hotpath.so; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: the HIP extension is not built. Run `python -m unclerenderer_amd.build`. "
+            "There is no CPU fallback for the hot path.")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class UrError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        msg = load().ur_last_error().decode(errors="replace")
+        super().__init__(f"{where} failed with {code}: {msg}")
+        self.code = code
+
+
+def check(code: int, where: str) -> None:
+    if code != UR_OK:
+        raise UrError(code, where)
+
+
+def fptr(a: np.ndarray):
+    """float32 numpy array -> float* (the array must stay alive for the duration of the call)."""
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_FP)
