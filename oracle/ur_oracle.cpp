@@ -408,6 +408,10 @@ float4 FetchCubeTexel(const EnvCube& c, uint32_t mip, int face, int i, int j)
 float3 SampleCubeBilinear(const EnvCube& c, uint32_t mip, const CubeFaceUV& f)
 {
     const float N = (float)std::max(1u, c.base >> mip);
+    if (!(f.u == f.u) || !(f.v == f.v)) { // NaN direction (cleared G-buffer pixel): every filter weight is NaN
+        const float n = std::numeric_limits<float>::quiet_NaN();
+        return {n, n, n};
+    }
     const float x = f.u * N - 0.5f, y = f.v * N - 0.5f;
     const float x0 = std::floor(x), y0 = std::floor(y);
     const float fx = x - x0, fy = y - y0;

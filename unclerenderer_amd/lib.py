@@ -120,6 +120,14 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{_LIB_PATH} is missing: the HIP extension is not built. Run `python -m unclerenderer_amd.build`. "
             "There is no CPU fallback for the hot path.")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7) but asks for it by file
+    # name, so if the system copy were loaded first the process would end up with two runtimes and the second one sees
+    # no device (KFD allows one open per process). Importing torch first makes our NEEDED libamdhip64.so.7 resolve to
+    # the copy torch already loaded. A C++ host that does not use torch simply gets /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
