@@ -48,6 +48,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from unclerenderer_amd import dist as urdist
     from unclerenderer_amd import hostmath, synth
     from unclerenderer_amd.hotpath import HotPath, HzbLayout, to_device
 
@@ -138,7 +139,7 @@ def main():
             e1.record()
             light_events.append((e0, e1))
         if N > 1:
-            dist.all_gather_into_tensor(s["hdr_full"].view(-1), s["hdr_band"].reshape(-1))
+            urdist.allgather_hdr(s["hdr_full"], s["hdr_band"])
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,67 @@
+/*
+ * ur_frame.h — C face of the render-graph-driven frame (csrc/frame/HotPathRenderer): the four hot passes added to an
+ * FRenderGraph in the reference's order and executed on the context's stream. This is what a host that does not link
+ * C++ (the Python tests, bench.py) calls; a C++ renderer uses FRenderGraph / FHotPathRenderer directly.
+ */
+#ifndef UR_FRAME_H
+#define UR_FRAME_H
+
+#include "ur_hotpath.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ur_frame ur_frame;
+
+/* All device pointers; band-local images hold rows [row0,row0+rows) of the width x height frame. */
+typedef struct ur_frame_resources {
+    uint32_t width, height, row0, rows;
+    const ur_half4* gbuffer_a;
+    const ur_half4* gbuffer_b;
+    const uint32_t* gbuffer_c;
+    const float* depth_band;
+    ur_half4* lighting_band;
+    const float* depth_full;      /* src of the (replicated) HZB build */
+    float* hzb;
+    ur_mip_desc hzb_mips[UR_MAX_HZB_MIPS];
+    uint32_t hzb_mip_count;
+    ur_lighting_tables tables;
+    const ur_float4* model_bounds;
+    void* indirect_args;
+    uint32_t indirect_command_count;
+    uint32_t instance_index_base;
+    uint32_t* visible_indices;    /* nullable */
+    uint32_t* visible_count;      /* nullable */
+    uint32_t* cull_stats;         /* nullable */
+} ur_frame_resources;
+
+#define UR_FRAME_INDIRECT_DRAW 0x1u
+#define UR_FRAME_HZB 0x2u
+#define UR_FRAME_DEPTH_PREPASS 0x4u
+#define UR_FRAME_SHADOWS 0x8u
+#define UR_FRAME_SKY 0x10u
+#define UR_FRAME_FUSE_LIGHTING_SKY 0x20u
+#define UR_FRAME_GPU_TIMING 0x40u
+#define UR_FRAME_GRAPH_DUMP 0x80u
+#define UR_FRAME_BARRIER_LOGS 0x100u
+#define UR_FRAME_DEFAULT (UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY)
+
+ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size);
+void ur_frame_destroy(ur_frame* f);
+/* One frame: BeginFrame, build the graph (GPU Culling, Build HZB, Lighting, Sky), Execute. culling_constants: the 46
+ * dwords of DispatchGpuCulling; dwords 40-44 (ModelCount, HZBEnabled, HZBMipCount, HZBWidth, HZBHeight) are overwritten
+ * from the resources and from whether last frame built an HZB (bHZBReady). */
+int ur_frame_render(ur_frame* f, const ur_frame_resources* res, const uint32_t* culling_constants, const ur_scene_constants* scene,
+                    const ur_sky_constants* sky, uint32_t option_flags);
+int ur_frame_hzb_ready(const ur_frame* f);
+void ur_frame_reset_hzb(ur_frame* f);
+/* Last execution: one line per pass "name|culled(0/1)|transitions". Returns bytes needed (incl. NUL). */
+uint32_t ur_frame_report(const ur_frame* f, char* buf, uint32_t cap);
+/* Sliding-window GPU timing (FRenderGraph::GetGpuTimingStats): "name|avg_ms|min_ms|max_ms|samples" lines. */
+uint32_t ur_rg_timing_stats(char* buf, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UR_FRAME_H */

@@ -1,0 +1,78 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares; host-only entry points behave (no GPU)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    names = set()
+    for h in (ROOT / "include").glob("*.h"):
+        text = re.sub(r"/\*.*?\*/", "", h.read_text(), flags=re.S)
+        names |= set(re.findall(r"\b(ur_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_every_declared_symbol_is_exported_and_bound(urlib):
+    from unclerenderer_amd import lib
+    decl = declared_symbols()
+    assert len(decl) >= 35
+    for name in sorted(decl):
+        assert hasattr(urlib, name), f"{name} declared in include/ but not exported"
+    assert decl == set(lib.SIGNATURES), (decl ^ set(lib.SIGNATURES))
+
+
+def test_struct_layouts(urlib):
+    from unclerenderer_amd import lib
+    assert C.sizeof(lib.SceneConstants) == 608  # sizeof(FSceneConstants), RendererUtils.h:41-79
+    assert C.sizeof(lib.SkyConstants) == 240    # sizeof(FSkyAtmosphereConstants)
+    assert lib.SceneConstants.LightViewProjection.offset == 336
+    assert lib.SceneConstants.ShadowStrength.offset == 400
+    assert lib.SceneConstants.EnvMapMipCount.offset == 576
+    assert C.sizeof(lib.MipDesc) == 12
+    assert lib.UR_INDIRECT_COMMAND_STRIDE == 64 and lib.UR_INDIRECT_INSTANCE_COUNT_OFFSET == 44
+
+
+def test_hzb_layout_matches_create_hzb_resources(urlib):
+    """CreateHZBResources (DeferredRenderer.cpp:2801-2835): chains listed in SURVEY.md §8 a10."""
+    from unclerenderer_amd.hotpath import HzbLayout
+    dims = lambda w, h: [(m[1], m[2]) for m in HzbLayout(w, h).as_list()]
+    assert dims(1920, 1080) == [(960, 540), (480, 270), (240, 135), (120, 67), (60, 33), (30, 16), (15, 8), (7, 4), (3, 2), (1, 1)]
+    assert len(dims(512, 512)) == 9 and dims(512, 512)[0] == (256, 256)
+    assert len(dims(3840, 2160)) == 11 and len(dims(7680, 4320)) == 12
+    assert dims(1, 1) == [(1, 1)] and dims(3, 5) == [(2, 3), (1, 1)]
+    lay = HzbLayout(3840, 2160)
+    assert sum(w * h for _, w, h in lay.as_list()) == 2764655
+    assert all(off % 64 == 0 for off, _, _ in lay.as_list())
+    mips = (urlib.ur_hzb_layout.argtypes[2]._type_ * 16)()
+    n = C.c_uint32(0)
+    assert urlib.ur_hzb_layout(0, 4, mips, C.byref(n)) == 0
+
+
+def test_env_cube_texels(urlib):
+    assert urlib.ur_env_cube_texels(256, 9) == 6 * sum((max(1, 256 >> m) + 2) ** 2 for m in range(9))
+    assert urlib.ur_env_cube_texels(0, 9) == 0 and urlib.ur_env_cube_texels(256, 17) == 0
+
+
+def test_no_gpu_fails_loudly(urlib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert not urlib.ur_create(0, None)
+    assert b"no HIP device" in urlib.ur_last_error()
+    from unclerenderer_amd.hotpath import HotPath
+    with pytest.raises(RuntimeError):
+        HotPath(0)
+
+
+def test_null_context_is_einval(urlib):
+    from unclerenderer_amd import lib
+    assert urlib.ur_build_hzb(None, None, 0, 0, None, None, 0) == lib.UR_EINVAL
+    assert urlib.ur_cull_indirect_args(None, None, None, None, None, None, None, None, None) == lib.UR_EINVAL
+    assert urlib.ur_reserve(None, 10) == lib.UR_EINVAL
+    assert urlib.ur_frame_render(None, None, None, None, None, 0) == lib.UR_EINVAL
+    assert b"gfx950" in urlib.ur_version()

@@ -1,0 +1,84 @@
+"""The render-graph-driven frame on the GPU (csrc/frame/HotPathRenderer.cpp through include/ur_frame.h): pass order,
+pass culling, the bHZBReady hand-over between frames (DeferredRenderer.cpp:519,1210) and parity of the outputs."""
+import numpy as np
+import pytest
+
+from tests.util import hdr_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frame_passes_and_parity(hotpath, oracle):
+    import torch
+    from unclerenderer_amd import hostmath, lib, synth
+    from unclerenderer_amd.hotpath import Frame, HzbLayout, to_device
+    w, h, n = 128, 72, 600
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=128, env_mip_count=5)
+    g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 31)
+    shadow, env, lut = synth.shadow_map_noise(128, 31), synth.env_cube_procedural(16, 5), synth.brdf_lut_procedural(64, 16)
+    tables = hotpath.make_tables(to_device(shadow), hotpath.stage_env_cube(env, 16, 5), 16, 5, to_device(lut))
+    lay = HzbLayout(w, h)
+    bounds = synth.instances_random(n, 31, center=fc.camera_position, box=60.0)
+    args0 = synth.indirect_args_initial(n)
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+    d_hzb = torch.zeros(lay.total, device="cuda")
+    d_args, d_stats = to_device(args0), torch.zeros(2, dtype=torch.int32, device="cuda")
+    d_vis, d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, True)  # dwords 40-44 are filled by the frame
+    frame = Frame(hotpath)
+
+    def render(flags, hdr):
+        res = Frame.resources(w, h, 0, h, dA, dB, dC, dD, hdr, dD, d_hzb, lay, tables, to_device(bounds), d_args, n, 0, d_vis, d_cnt, d_stats)
+        frame.render(res, consts, fc.scene, fc.sky, flags)
+        torch.cuda.synchronize()
+
+    ref_hzb = np.nan_to_num(oracle.build_hzb(g.depth, lay.as_list(), lay.total))
+    lit, frag = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 16, 5, lut, g.hdr, w, h, want_fragile=True)
+    ref_hdr = oracle.sky_atmosphere(fc.sky, g.depth, lit, w, h)
+
+    # ---- frame 1: no HZB yet -> frustum-only cull; HZB is built for the next frame
+    assert not frame.hzb_ready
+    hdr1 = to_device(g.hdr)
+    render(lib.UR_FRAME_DEFAULT, hdr1)
+    rep = frame.report()
+    assert [r[0] for r in rep] == ["GPU Culling", "Build HZB", "Lighting", "Sky"]
+    assert not any(r[1] for r in rep)
+    assert frame.hzb_ready
+    c_nohzb = hostmath.pack_culling_constants(fc.view, fc.proj, n, False, lay.count, lay.width, lay.height, True)
+    ref_args, ref_stats, ref_vis, ref_cnt = oracle.cull_indirect_args(c_nohzb, bounds, None, lay.as_list(), args0)
+    assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args)
+    assert int(d_cnt.cpu()[0]) == ref_cnt
+    assert np.array_equal(d_hzb.cpu().numpy().view(np.uint32), ref_hzb.view(np.uint32))
+    nbad, worst, _ = hdr_mismatch(hdr1.cpu().numpy().view(np.uint16), ref_hdr, exclude=frag)
+    assert nbad == 0, (nbad, worst)
+    # state tracking: Depth DEPTH_WRITE->SRV (Build HZB), then ->DEPTH_READ (Sky); G-buffers RT->PSR; shadow ->PSR
+    tr = {r[0]: r[2] for r in rep}
+    assert tr["GPU Culling"] == 0 and tr["Build HZB"] == 1 and tr["Lighting"] == 4 and tr["Sky"] == 1
+
+    # ---- frame 2: last frame's HZB drives occlusion culling
+    d_args.copy_(to_device(args0)); d_stats.zero_()
+    hdr2 = to_device(g.hdr)
+    render(lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY, hdr2)
+    rep = frame.report()
+    assert [(r[0], r[1]) for r in rep] == [("GPU Culling", False), ("Build HZB", False), ("Lighting", False), ("Sky", True)]
+    c_hzb = hostmath.pack_culling_constants(fc.view, fc.proj, n, True, lay.count, lay.width, lay.height, True)
+    ref_args2, ref_stats2, ref_vis2, ref_cnt2 = oracle.cull_indirect_args(c_hzb, bounds, ref_hzb, lay.as_list(), args0)
+    assert ref_stats2[1] > 0, "fixture must exercise occlusion"
+    assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args2)
+    assert np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt2], ref_vis2)
+    assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats2)
+    assert torch.equal(hdr1, hdr2), "fused Lighting+Sky pass must equal Lighting followed by Sky"
+    assert {r[0]: r[2] for r in rep}["GPU Culling"] == 1  # HZB UAV -> NON_PIXEL_SHADER_RESOURCE
+
+    # ---- HZB disabled: the pass is not even added and readiness drops (DeferredRenderer.cpp:514-517)
+    render(lib.UR_FRAME_DEFAULT & ~lib.UR_FRAME_HZB, to_device(g.hdr))
+    assert [r[0] for r in frame.report()] == ["GPU Culling", "Lighting", "Sky"] and not frame.hzb_ready
+    # ---- indirect draw off: the culling pass declares nothing and is culled by the graph
+    render(lib.UR_FRAME_DEFAULT & ~lib.UR_FRAME_INDIRECT_DRAW, to_device(g.hdr))
+    assert frame.report()[0] == ("GPU Culling", True, 0)
+    # ---- GPU timing: event pairs per pass, harvested when the slot comes round again
+    for _ in range(8):
+        render(lib.UR_FRAME_DEFAULT | lib.UR_FRAME_GPU_TIMING, to_device(g.hdr))
+    names = {t[0] for t in frame.timing_stats()}
+    assert {"GPU Culling", "Build HZB", "Lighting", "Sky"} <= names
+    frame.close()

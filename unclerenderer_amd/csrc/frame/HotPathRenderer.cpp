@@ -1,0 +1,246 @@
+// HotPathRenderer.cpp — pass wiring of the hot path on FRenderGraph (see HotPathRenderer.h for reference citations).
+
+#include "HotPathRenderer.h"
+
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "../../../include/ur_frame.h"
+
+int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Res, const FHotPathFrameConstants& Constants,
+                                  const FHotPathOptions& Options)
+{
+    PassError = UR_OK;
+    FRenderGraph Graph;
+    Graph.SetDevice(Device);
+    Graph.SetGpuTimingEnabled(Options.bGpuTiming);
+    Graph.SetGraphDumpEnabled(Options.bGraphDump);
+    Graph.SetResourceLifetimeLogging(Options.bGraphDump);
+    Graph.SetBarrierLoggingEnabled(Options.bBarrierLogs);
+
+    const uint32 HZBWidth = Res.HZBMipCount ? Res.HZBMips[0].width : 0, HZBHeight = Res.HZBMipCount ? Res.HZBMips[0].height : 0;
+
+    // External resources, imported with a pointer to the owner's state variable (DeferredRenderer.cpp:437-506).
+    const FRGResourceHandle DepthHandle = Graph.ImportTexture("Depth", Res.DepthFull, &Res.DepthState, {Res.Width, Res.Height, RG_FORMAT_R32_FLOAT});
+    FRGResourceHandle GBufferHandles[3];
+    GBufferHandles[0] = Graph.ImportTexture("GBufferA", Res.GBufferA, &Res.GBufferStates[0], {Res.Width, Res.Rows, RG_FORMAT_R16G16B16A16_FLOAT});
+    GBufferHandles[1] = Graph.ImportTexture("GBufferB", Res.GBufferB, &Res.GBufferStates[1], {Res.Width, Res.Rows, RG_FORMAT_R16G16B16A16_FLOAT});
+    GBufferHandles[2] = Graph.ImportTexture("GBufferC", Res.GBufferC, &Res.GBufferStates[2], {Res.Width, Res.Rows, RG_FORMAT_R8G8B8A8_UNORM_SRGB});
+    const FRGResourceHandle ShadowHandle = Graph.ImportTexture("ShadowMap", const_cast<float*>(Res.Tables.shadow_map), &Res.ShadowState,
+                                                               {static_cast<uint32>(Constants.Scene.ShadowMapSize[0]), static_cast<uint32>(Constants.Scene.ShadowMapSize[1]), RG_FORMAT_R32_FLOAT});
+    const FRGResourceHandle LightingHandle = Graph.ImportTexture("Lighting", Res.LightingBand, &Res.LightingState, {Res.Width, Res.Rows, RG_FORMAT_R16G16B16A16_FLOAT});
+    const FRGResourceHandle HZBHandle = Graph.ImportTexture("HZB", Res.HZB, &Res.HZBState, {HZBWidth, HZBHeight, RG_FORMAT_R32_FLOAT});
+
+    const bool bHZBEnabled = Options.bHZBEnabled && Res.HZB != nullptr && Res.HZBMipCount != 0;
+    if (!bHZBEnabled) bHZBReady = false; // :514-517
+    const bool bUseHZBOcclusion = bHZBEnabled && bHZBReady; // ConfigureHZBOcclusion, :519-520
+
+    // ---- GPU Culling (first pass of the frame; uses LAST frame's HZB with the current camera) --------------------
+    struct FGpuCullingPassData
+    {
+        bool bEnabled = false;
+        uint32 Constants[UR_CULL_CONSTANT_DWORDS] = {};
+    };
+    Graph.AddPass<FGpuCullingPassData>("GPU Culling", [&](FGpuCullingPassData& Data, FRGPassBuilder& Builder)
+    {
+        Data.bEnabled = Options.bEnableIndirectDraw && Res.IndirectArgs && Res.ModelBounds && Res.IndirectCommandCount != 0;
+        std::memcpy(Data.Constants, Constants.CullingConstants, sizeof(Data.Constants));
+        Data.Constants[40] = Res.IndirectCommandCount;
+        Data.Constants[41] = bUseHZBOcclusion ? 1u : 0u;
+        Data.Constants[42] = Res.HZBMipCount;
+        Data.Constants[43] = HZBWidth;
+        Data.Constants[44] = HZBHeight;
+        if (Data.bEnabled) {
+            if (bUseHZBOcclusion) Builder.ReadTexture(HZBHandle, RG_STATE_NON_PIXEL_SHADER_RESOURCE);
+            Builder.KeepAlive();
+        }
+    }, [this, &Res](const FGpuCullingPassData& Data, FHIPCommandContext& Cmd)
+    {
+        if (!Data.bEnabled) return;
+        // DispatchGpuCulling (Renderer.cpp:394-472): the UAV / INDIRECT_ARGUMENT transitions are stream order here.
+        const int rc = ur_cull_indirect_args_ex(Cmd.GetContext(), Data.Constants, Res.ModelBounds, Res.HZB, Res.HZBMips, Res.IndirectArgs, Res.CullStats,
+                                                Res.VisibleIndices, Res.VisibleCount, Res.InstanceIndexBase);
+        if (rc != UR_OK && PassError == UR_OK) PassError = rc;
+    });
+
+    // ---- Build HZB (after the G-buffer pass; only with HZB and depth prepass enabled, :996) ------------------------
+    struct FHZBPassData
+    {
+        uint32 Width = 0, Height = 0, MipCount = 0, SourceWidth = 0, SourceHeight = 0;
+    };
+    if (bHZBEnabled && Options.bDoDepthPrepass) {
+        Graph.AddPass<FHZBPassData>("Build HZB", [&](FHZBPassData& Data, FRGPassBuilder& Builder)
+        {
+            Data.Width = HZBWidth;
+            Data.Height = HZBHeight;
+            Data.MipCount = Res.HZBMipCount;
+            Data.SourceWidth = Res.Width;
+            Data.SourceHeight = Res.Height;
+            Builder.ReadTexture(DepthHandle, RG_STATE_NON_PIXEL_SHADER_RESOURCE);
+            Builder.WriteTexture(HZBHandle, RG_STATE_UNORDERED_ACCESS);
+        }, [this, &Res](const FHZBPassData& Data, FHIPCommandContext& Cmd)
+        {
+            if (Data.MipCount == 0) return;
+            const int rc = ur_build_hzb(Cmd.GetContext(), Res.DepthFull, Data.SourceWidth, Data.SourceHeight, Res.HZB, Res.HZBMips, Data.MipCount);
+            if (rc != UR_OK && PassError == UR_OK) PassError = rc;
+            Res.HZBState = RG_STATE_NON_PIXEL_SHADER_RESOURCE; // :1209
+            if (rc == UR_OK) bHZBReady = true;                  // :1210
+        });
+    }
+
+    const bool bSky = Options.bSkyEnabled && Res.DepthBand != nullptr;
+    const bool bFused = Options.bFuseLightingAndSky && bSky;
+
+    // ---- Lighting (fullscreen, additive) --------------------------------------------------------------------------
+    struct FLightingPassData
+    {
+        bool bUseShadows = false;
+        bool bFusedSky = false;
+        ur_scene_constants Scene;
+        ur_sky_constants Sky;
+    };
+    Graph.AddPass<FLightingPassData>("Lighting", [&](FLightingPassData& Data, FRGPassBuilder& Builder)
+    {
+        Data.bUseShadows = Options.bRenderShadows;
+        Data.bFusedSky = bFused;
+        Data.Scene = Constants.Scene;
+        Data.Sky = Constants.Sky;
+        if (!Data.bUseShadows) Data.Scene.ShadowStrength = 0.0f; // bShadowsEnabled ? ShadowStrength : 0 (:3777)
+        Builder.ReadTexture(GBufferHandles[0], RG_STATE_PIXEL_SHADER_RESOURCE);
+        Builder.ReadTexture(GBufferHandles[1], RG_STATE_PIXEL_SHADER_RESOURCE);
+        Builder.ReadTexture(GBufferHandles[2], RG_STATE_PIXEL_SHADER_RESOURCE);
+        if (Data.bUseShadows) Builder.ReadTexture(ShadowHandle, RG_STATE_PIXEL_SHADER_RESOURCE);
+        if (Data.bFusedSky) Builder.ReadTexture(DepthHandle, RG_STATE_DEPTH_READ);
+        Builder.WriteTexture(LightingHandle, RG_STATE_RENDER_TARGET);
+    }, [this, &Res](const FLightingPassData& Data, FHIPCommandContext& Cmd)
+    {
+        int rc;
+        if (Data.bFusedSky)
+            rc = ur_deferred_lighting_sky(Cmd.GetContext(), &Data.Scene, &Data.Sky, Res.GBufferA, Res.GBufferB, Res.GBufferC, Res.DepthBand, &Res.Tables,
+                                          Res.LightingBand, Res.Width, Res.Height, Res.Row0, Res.Rows);
+        else
+            rc = ur_deferred_lighting(Cmd.GetContext(), &Data.Scene, Res.GBufferA, Res.GBufferB, Res.GBufferC, &Res.Tables, Res.LightingBand, Res.Width,
+                                      Res.Height, Res.Row0, Res.Rows);
+        if (rc != UR_OK && PassError == UR_OK) PassError = rc;
+    });
+
+    // ---- Sky --------------------------------------------------------------------------------------------------------
+    struct FSkyPassData
+    {
+        bool bEnabled = false;
+        ur_sky_constants Sky;
+    };
+    Graph.AddPass<FSkyPassData>("Sky", [&](FSkyPassData& Data, FRGPassBuilder& Builder)
+    {
+        Data.bEnabled = bSky && !bFused;
+        Data.Sky = Constants.Sky;
+        if (Data.bEnabled) {
+            Builder.ReadTexture(DepthHandle, RG_STATE_DEPTH_READ);
+            Builder.WriteTexture(LightingHandle, RG_STATE_RENDER_TARGET);
+        }
+    }, [this, &Res](const FSkyPassData& Data, FHIPCommandContext& Cmd)
+    {
+        if (!Data.bEnabled) return;
+        const int rc = ur_sky_atmosphere(Cmd.GetContext(), &Data.Sky, Res.DepthBand, Res.LightingBand, Res.Width, Res.Height, Res.Row0, Res.Rows);
+        if (rc != UR_OK && PassError == UR_OK) PassError = rc;
+    });
+
+    Graph.Execute(Cmd);
+    LastReport = Graph.GetLastExecutionReport();
+    return PassError;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C face
+// ---------------------------------------------------------------------------------------------------------------------
+struct ur_frame
+{
+    FHIPDevice Device;
+    FHIPCommandContext Cmd;
+    FHotPathRenderer Renderer;
+    FHotPathResources Res;
+    ur_frame(ur_ctx* Ctx, hipStream_t Stream, uint32 Frames, int Rank, int World) : Cmd(Ctx, Stream, Frames, Rank, World), Renderer(&Device) {}
+};
+
+extern "C" {
+
+ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size)
+{
+    if (!ctx) return nullptr;
+    return new ur_frame(ctx, static_cast<hipStream_t>(stream), frames_in_flight, rank, world_size);
+}
+
+void ur_frame_destroy(ur_frame* f) { delete f; }
+
+int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* culling_constants, const ur_scene_constants* scene,
+                    const ur_sky_constants* sky, uint32_t flags)
+{
+    if (!f || !r || !culling_constants || !scene || !sky) return UR_EINVAL;
+    FHotPathResources& R = f->Res; // resource states persist across frames, like the renderer's member variables
+    R.Width = r->width; R.Height = r->height; R.Row0 = r->row0; R.Rows = r->rows;
+    R.GBufferA = const_cast<ur_half4*>(r->gbuffer_a);
+    R.GBufferB = const_cast<ur_half4*>(r->gbuffer_b);
+    R.GBufferC = const_cast<uint32*>(r->gbuffer_c);
+    R.DepthBand = const_cast<float*>(r->depth_band);
+    R.LightingBand = r->lighting_band;
+    R.DepthFull = const_cast<float*>(r->depth_full);
+    R.HZB = r->hzb;
+    std::memcpy(R.HZBMips, r->hzb_mips, sizeof(R.HZBMips));
+    R.HZBMipCount = r->hzb_mip_count;
+    R.Tables = r->tables;
+    R.ModelBounds = const_cast<ur_float4*>(r->model_bounds);
+    R.IndirectArgs = r->indirect_args;
+    R.IndirectCommandCount = r->indirect_command_count;
+    R.InstanceIndexBase = r->instance_index_base;
+    R.VisibleIndices = r->visible_indices;
+    R.VisibleCount = r->visible_count;
+    R.CullStats = r->cull_stats;
+
+    FHotPathFrameConstants K;
+    std::memcpy(K.CullingConstants, culling_constants, sizeof(K.CullingConstants));
+    K.Scene = *scene;
+    K.Sky = *sky;
+    FHotPathOptions O;
+    O.bEnableIndirectDraw = (flags & UR_FRAME_INDIRECT_DRAW) != 0;
+    O.bHZBEnabled = (flags & UR_FRAME_HZB) != 0;
+    O.bDoDepthPrepass = (flags & UR_FRAME_DEPTH_PREPASS) != 0;
+    O.bRenderShadows = (flags & UR_FRAME_SHADOWS) != 0;
+    O.bSkyEnabled = (flags & UR_FRAME_SKY) != 0;
+    O.bFuseLightingAndSky = (flags & UR_FRAME_FUSE_LIGHTING_SKY) != 0;
+    O.bGpuTiming = (flags & UR_FRAME_GPU_TIMING) != 0;
+    O.bGraphDump = (flags & UR_FRAME_GRAPH_DUMP) != 0;
+    O.bBarrierLogs = (flags & UR_FRAME_BARRIER_LOGS) != 0;
+    f->Cmd.BeginFrame();
+    return f->Renderer.RenderFrame(f->Cmd, R, K, O);
+}
+
+int ur_frame_hzb_ready(const ur_frame* f) { return f && f->Renderer.IsHZBReady() ? 1 : 0; }
+void ur_frame_reset_hzb(ur_frame* f) { if (f) f->Renderer.ResetHZB(); }
+
+static uint32_t copy_out(const std::string& s, char* buf, uint32_t cap)
+{
+    if (buf && cap) {
+        const size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return static_cast<uint32_t>(s.size() + 1);
+}
+
+uint32_t ur_frame_report(const ur_frame* f, char* buf, uint32_t cap)
+{
+    std::ostringstream s;
+    if (f)
+        for (const auto& p : f->Renderer.GetLastReport()) s << p.Name << '|' << (p.bCulled ? 1 : 0) << '|' << p.Transitions << '\n';
+    return copy_out(s.str(), buf, cap);
+}
+
+uint32_t ur_rg_timing_stats(char* buf, uint32_t cap)
+{
+    std::ostringstream s;
+    for (const auto& t : FRenderGraph::GetGpuTimingStats()) s << t.Name << '|' << t.AvgMs << '|' << t.MinMs << '|' << t.MaxMs << '|' << t.SampleCount << '\n';
+    return copy_out(s.str(), buf, cap);
+}
+
+} // extern "C"

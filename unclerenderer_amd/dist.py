@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests). The reference is single-GPU; this is new design:
+
+  * DeferredLighting/Sky: contiguous row bands, rank r shades rows [r*H/N, (r+1)*H/N); ONE all-gather of the RGBA16F
+    bands per frame rebuilds the full HDR buffer on every rank (equal counts, N | H).
+  * CullIndirectArgs: contiguous instance ranges; the per-rank visible lists are already ascending and carry global
+    indices (index_base), so concatenating them in rank order is the single-GPU list bit for bit. Counts are
+    all-gathered first, then the lists are all-gathered padded to the largest count.
+  * BuildHZB: replicated (every rank builds the full chain from the full depth) — no exchange.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class BandPlan:
+    rank: int
+    world: int
+    height: int
+    row0: int
+    rows: int
+
+
+def plan_bands(height: int, world: int, rank: int) -> BandPlan:
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank {rank} of {world}")
+    if height % world != 0:
+        raise ValueError(f"frame height {height} is not divisible by {world} ranks (the HDR all-gather needs equal bands)")
+    rows = height // world
+    return BandPlan(rank, world, height, rank * rows, rows)
+
+
+def plan_instances(count: int, world: int, rank: int) -> tuple[int, int]:
+    """[first, last) of the contiguous instance range of `rank` (sizes differ by at most one)."""
+    return rank * count // world, (rank + 1) * count // world
+
+
+def allgather_hdr(hdr_full: torch.Tensor, band: torch.Tensor, group=None) -> None:
+    """hdr_full: (H, W, 4) 16-bit tensor on every rank; band: this rank's (H/N, W, 4) rows. One collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if band.data_ptr() != hdr_full.data_ptr():
+            hdr_full.copy_(band.view_as(hdr_full))
+        return
+    # transported as bytes: neither RCCL nor gloo has a 16-bit integer type, and the payload is opaque fp16 bit patterns
+    dist.all_gather_into_tensor(hdr_full.view(torch.uint8).view(-1), band.contiguous().view(torch.uint8).view(-1), group=group)
+
+
+def allgather_visible(visible_idx: torch.Tensor, visible_count: torch.Tensor, group=None) -> tuple[torch.Tensor, int]:
+    """Concatenate the per-rank ascending visible lists in rank order. visible_idx holds global indices (index_base);
+    visible_count is a 1-element integer tensor. Returns (list, total)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        n = int(visible_count.item())
+        return visible_idx[:n].clone(), n
+    world = dist.get_world_size(group)
+    counts = torch.zeros(world, dtype=visible_count.dtype, device=visible_count.device)
+    dist.all_gather_into_tensor(counts, visible_count.reshape(1), group=group)
+    counts_host = [int(c) for c in counts.cpu()]
+    cap = max(max(counts_host), 1)
+    send = torch.zeros(cap, dtype=visible_idx.dtype, device=visible_idx.device)
+    n = counts_host[dist.get_rank(group)]
+    send[:n] = visible_idx[:n]
+    recv = torch.zeros(world * cap, dtype=visible_idx.dtype, device=visible_idx.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    parts = [recv[r * cap: r * cap + counts_host[r]] for r in range(world)]
+    return torch.cat(parts), sum(counts_host)

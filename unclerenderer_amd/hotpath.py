@@ -131,6 +131,78 @@ class HotPath:
                                                     _ptr(hdr), w, h, row0, rows), "ur_deferred_lighting_sky")
 
 
+class Frame:
+    """The render-graph-driven frame (csrc/frame/HotPathRenderer.cpp): GPU Culling -> Build HZB -> Lighting -> Sky added to
+    an FRenderGraph in the reference's order and executed on the context's stream."""
+
+    def __init__(self, hp: HotPath, frames_in_flight: int = 3, rank: int = 0, world_size: int = 1):
+        self._hp = hp
+        self._L = hp._L
+        self._f = self._L.ur_frame_create(hp.ctx, C.c_void_p(hp.stream.cuda_stream), frames_in_flight, rank, world_size)
+        if not self._f:
+            raise RuntimeError("ur_frame_create failed")
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_f", None):
+            self._L.ur_frame_destroy(self._f)
+            self._f = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def resources(w, h, row0, rows, A, B, Cc, depth_band, lighting_band, depth_full, hzb, layout: HzbLayout, tables, bounds=None,
+                  indirect_args=None, command_count=0, index_base=0, visible_idx=None, visible_count=None, cull_stats=None):
+        r = _lib.FrameResources()
+        r.width, r.height, r.row0, r.rows = w, h, row0, rows
+        dp = lambda t: t.data_ptr() if t is not None else None
+        r.gbuffer_a, r.gbuffer_b, r.gbuffer_c = dp(A), dp(B), dp(Cc)
+        r.depth_band, r.lighting_band, r.depth_full, r.hzb = dp(depth_band), dp(lighting_band), dp(depth_full), dp(hzb)
+        if layout is not None:
+            for i in range(layout.count):
+                r.hzb_mips[i] = layout.mips[i]
+            r.hzb_mip_count = layout.count
+        r.tables = tables
+        r.model_bounds, r.indirect_args = dp(bounds), dp(indirect_args)
+        r.indirect_command_count, r.instance_index_base = command_count, index_base
+        r.visible_indices, r.visible_count, r.cull_stats = dp(visible_idx), dp(visible_count), dp(cull_stats)
+        r._keep = (A, B, Cc, depth_band, lighting_band, depth_full, hzb, tables, bounds, indirect_args, visible_idx, visible_count, cull_stats)
+        return r
+
+    def render(self, res, culling_constants: np.ndarray, scene, sky, flags: int = _lib.UR_FRAME_DEFAULT):
+        cc = np.ascontiguousarray(culling_constants, np.uint32)
+        _lib.check(self._L.ur_frame_render(self._f, C.byref(res), cc.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(scene), C.byref(sky), flags),
+                   "ur_frame_render")
+
+    @property
+    def hzb_ready(self) -> bool:
+        return bool(self._L.ur_frame_hzb_ready(self._f))
+
+    def reset_hzb(self):
+        self._L.ur_frame_reset_hzb(self._f)
+
+    def report(self):
+        """[(pass name, culled, transitions)] of the last executed graph."""
+        n = self._L.ur_frame_report(self._f, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.ur_frame_report(self._f, buf, n)
+        out = []
+        for line in buf.value.decode().splitlines():
+            name, culled, tr = line.split("|")
+            out.append((name, culled == "1", int(tr)))
+        return out
+
+    def timing_stats(self):
+        n = self._L.ur_rg_timing_stats(None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.ur_rg_timing_stats(buf, n)
+        return [tuple(l.split("|")) for l in buf.value.decode().splitlines()]
+
+
 def to_device(a: np.ndarray, device=0) -> torch.Tensor:
     """numpy -> device tensor, reinterpreting unsigned dtypes torch cannot hold (bit patterns are preserved)."""
     a = np.ascontiguousarray(a)

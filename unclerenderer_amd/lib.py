@@ -63,6 +63,23 @@ class LightingTables(C.Structure):
     ]
 
 
+class FrameResources(C.Structure):
+    """ur_frame_resources (include/ur_frame.h)."""
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("row0", C.c_uint32), ("rows", C.c_uint32),
+        ("gbuffer_a", C.c_void_p), ("gbuffer_b", C.c_void_p), ("gbuffer_c", C.c_void_p), ("depth_band", C.c_void_p),
+        ("lighting_band", C.c_void_p), ("depth_full", C.c_void_p), ("hzb", C.c_void_p),
+        ("hzb_mips", MipDesc * UR_MAX_HZB_MIPS), ("hzb_mip_count", C.c_uint32),
+        ("tables", LightingTables),
+        ("model_bounds", C.c_void_p), ("indirect_args", C.c_void_p), ("indirect_command_count", C.c_uint32),
+        ("instance_index_base", C.c_uint32), ("visible_indices", C.c_void_p), ("visible_count", C.c_void_p), ("cull_stats", C.c_void_p),
+    ]
+
+
+UR_FRAME_INDIRECT_DRAW, UR_FRAME_HZB, UR_FRAME_DEPTH_PREPASS, UR_FRAME_SHADOWS, UR_FRAME_SKY = 0x1, 0x2, 0x4, 0x8, 0x10
+UR_FRAME_FUSE_LIGHTING_SKY, UR_FRAME_GPU_TIMING, UR_FRAME_GRAPH_DUMP, UR_FRAME_BARRIER_LOGS = 0x20, 0x40, 0x80, 0x100
+UR_FRAME_DEFAULT = UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY
+
 assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
 
 # name -> (restype, argtypes); every symbol declared in include/*.h
@@ -86,6 +103,14 @@ SIGNATURES = {
     "ur_deferred_lighting_sky": (C.c_int, [_VP, C.POINTER(SceneConstants), C.POINTER(SkyConstants), _VP, _VP, _VP, _VP,
                                            C.POINTER(LightingTables), _VP, _U32, _U32, _U32, _U32]),
     "ur_allgather_rows": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
+    # ur_frame.h
+    "ur_frame_create": (_VP, [_VP, _VP, _U32, C.c_int, C.c_int]),
+    "ur_frame_destroy": (None, [_VP]),
+    "ur_frame_render": (C.c_int, [_VP, C.POINTER(FrameResources), C.POINTER(_U32), C.POINTER(SceneConstants), C.POINTER(SkyConstants), _U32]),
+    "ur_frame_hzb_ready": (C.c_int, [_VP]),
+    "ur_frame_reset_hzb": (None, [_VP]),
+    "ur_frame_report": (_U32, [_VP, C.c_char_p, _U32]),
+    "ur_rg_timing_stats": (_U32, [C.c_char_p, _U32]),
     # ur_host.h
     "ur_host_look_to_lh": (None, [_FP, _FP, _FP, _FP]),
     "ur_host_look_at_lh": (None, [_FP, _FP, _FP, _FP]),
