@@ -68,7 +68,10 @@ def test_frame_passes_and_parity(hotpath, oracle):
     assert np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt2], ref_vis2)
     assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats2)
     assert torch.equal(hdr1, hdr2), "fused Lighting+Sky pass must equal Lighting followed by Sky"
-    assert {r[0]: r[2] for r in rep}["GPU Culling"] == 1  # HZB UAV -> NON_PIXEL_SHADER_RESOURCE
+    # the Build HZB lambda leaves HZBState = NON_PIXEL_SHADER_RESOURCE (DeferredRenderer.cpp:1209), so the cull pass needs
+    # no transition; Build HZB takes it back to UNORDERED_ACCESS and Depth from DEPTH_READ back to an SRV state
+    tr = {r[0]: r[2] for r in rep}
+    assert tr["GPU Culling"] == 0 and tr["Build HZB"] == 2
 
     # ---- HZB disabled: the pass is not even added and readiness drops (DeferredRenderer.cpp:514-517)
     render(lib.UR_FRAME_DEFAULT & ~lib.UR_FRAME_HZB, to_device(g.hdr))
