@@ -13,17 +13,21 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
-def time_events(torch, fn, iters, warm=5):
+def time_events(torch, fn, iters, warm=5, reps=7):
+    """Back-to-back launches between ONE event pair (steady-state per-launch time), repeated; returns (median, min) us."""
     for _ in range(warm):
         fn(0)
-    evs = []
-    for k in range(iters):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(k); b.record()
-        evs.append((a, b))
     torch.cuda.synchronize()
-    t = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
-    return float(np.median(t)), float(t.min())
+    out = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for k in range(iters):
+            fn(k)
+        b.record()
+        torch.cuda.synchronize()
+        out.append(a.elapsed_time(b) * 1e3 / iters)
+    return float(np.median(out)), float(min(out))
 
 
 def main():

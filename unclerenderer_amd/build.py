@@ -30,7 +30,7 @@ SOURCES = [
     ("ur_api.hip", []),
     ("hzb.hip", EXACT),
     ("cull.hip", EXACT),
-    ("lighting.hip", []),
+    ("lighting.hip", ["-fno-slp-vectorize"]),  # packed fp32 VALU ops are not faster on gfx950 and cost v_mov traffic
     ("host_math.cpp", ["-x", "hip"] + EXACT),
     ("rg/RenderGraph.cpp", ["-x", "hip"]),
     ("frame/HotPathRenderer.cpp", ["-x", "hip"]),

@@ -42,6 +42,8 @@ struct LightingParams {
     float maxMip;        // max(0, EnvMapMipCount-1)
     uint32_t envBase, envMips;
     uint32_t envMipOffset[16]; // in half4 texels
+    uint32_t irrOffset0, irrOffset1, irrN0, irrN1; // mip pair of the irradiance lookup (level == maxMip, launch-uniform)
+    float irrFrac;
     uint32_t lutW, lutH;
     // sky
     float skyRot[9];     // rows of View's 3x3: world_j = dot(skyRot[3j..3j+2], v)
@@ -68,6 +70,22 @@ __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x);
 __device__ __forceinline__ float sat(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 __device__ __forceinline__ float mix(float a, float b, float t) { return fmaf(t, b - a, a); }
 
+// base + 32-bit unsigned BYTE offset: lets the compiler use the SGPR-base + VGPR-offset addressing mode of global_load
+// instead of 64-bit VALU address arithmetic (v_lshl_add_u64 per access).
+template <class T>
+__device__ __forceinline__ T ld(const void* base, uint32_t byte_offset)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
+}
+template <class T>
+__device__ __forceinline__ void st(void* base, uint32_t byte_offset, T v)
+{
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_offset) = v;
+}
+
+struct __attribute__((packed, aligned(8))) uint4u { uint32_t x, y, z, w; }; // 16 bytes, 8-byte aligned
+struct __attribute__((packed, aligned(4))) float3u { float x, y, z; };      // 12 bytes, 4-byte aligned
+
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { return {x, y, z}; }
 __device__ __forceinline__ float dot(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
@@ -81,67 +99,74 @@ __device__ __forceinline__ F3 rot(F3 v, const float* M)
 
 // ---- bordered cube: face f of mip m is (N+2)^2 texels, border = seamless neighbours (ur_stage_env_cube) -----------
 struct CubeUV { uint32_t face; float u, v; };
+// D3D cube addressing (+X,-X,+Y,-Y,+Z,-Z; ties z > y > x; uc/vc table of the oracle's SelectCubeFace) is exactly what
+// gfx950's v_cubeid/v_cubesc/v_cubetc/v_cubema compute (cubema = 2 * signed major axis), four instructions instead of a
+// compare/select ladder.
 __device__ __forceinline__ CubeUV cube_face(F3 d)
 {
-    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    const bool zmaj = az >= ax && az >= ay;
-    const bool ymaj = !zmaj && ay >= ax;
-    // major component, and the (uc, vc) pair of the D3D cube table
-    const float m = zmaj ? d.z : (ymaj ? d.y : d.x);
-    const bool pos = m >= 0.0f;
-    float uc = zmaj ? d.x : (ymaj ? d.x : -d.z);
-    float vc = ymaj ? d.z : -d.y;
-    // sign flips: +Z uc=x, -Z uc=-x; +Y vc=z, -Y vc=-z; +X uc=-z, -X uc=z
-    if (!ymaj) uc = pos ? uc : -uc;
-    if (ymaj) vc = pos ? vc : -vc;
     CubeUV r;
-    r.face = (zmaj ? 4u : (ymaj ? 2u : 0u)) + (pos ? 0u : 1u);
-    const float inv = 0.5f * rcp(fabsf(m));
-    r.u = fmaf(uc, inv, 0.5f);
-    r.v = fmaf(vc, inv, 0.5f);
+    r.face = (uint32_t)__builtin_amdgcn_cubeid(d.x, d.y, d.z);
+    const float inv = rcp(fabsf(__builtin_amdgcn_cubema(d.x, d.y, d.z))); // 1 / (2 |major|)
+    r.u = fmaf(__builtin_amdgcn_cubesc(d.x, d.y, d.z), inv, 0.5f);
+    r.v = fmaf(__builtin_amdgcn_cubetc(d.x, d.y, d.z), inv, 0.5f);
     return r;
 }
 
-// bilinear taps of one mip: 4 x 8-byte loads, weights applied with mixed-precision FMAs
-__device__ __forceinline__ F3 cube_bilinear(const LightingParams& p, uint32_t mip, const CubeUV& c, float scale)
+// acc += w * f16(lo/hi half of a packed dword): one mixed-precision FMA, no unpack/convert instructions
+__device__ __forceinline__ float mix_lo(float acc, uint32_t packed, float w)
 {
-    const uint32_t N = max(1u, p.envBase >> mip), E = N + 2u;
-    const float fN = (float)N;
-    const float x = fmaf(c.u, fN, 0.5f), y = fmaf(c.v, fN, 0.5f); // bordered coordinates
-    const float x0 = floorf(x), y0 = floorf(y);
-    const float fx = x - x0, fy = y - y0;
-    const uint32_t i0 = min((uint32_t)max((int)x0, 0), N), j0 = min((uint32_t)max((int)y0, 0), N);
-    const half4_t* t = p.env + p.envMipOffset[mip] + (c.face * E + j0) * E + i0;
-    const half4_t t00 = t[0], t10 = t[1], t01 = t[E], t11 = t[E + 1];
-    const float wy1 = fy * scale, wy0 = scale - wy1;
-    const float w00 = wy0 - wy0 * fx, w10 = wy0 * fx, w01 = wy1 - wy1 * fx, w11 = wy1 * fx;
-    F3 r;
-    r.x = fmaf(w11, (float)t11.x, fmaf(w01, (float)t01.x, fmaf(w10, (float)t10.x, w00 * (float)t00.x)));
-    r.y = fmaf(w11, (float)t11.y, fmaf(w01, (float)t01.y, fmaf(w10, (float)t10.y, w00 * (float)t00.y)));
-    r.z = fmaf(w11, (float)t11.z, fmaf(w01, (float)t01.z, fmaf(w10, (float)t10.z, w00 * (float)t00.z)));
-    return r;
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+    return acc;
+}
+__device__ __forceinline__ float mix_hi(float acc, uint32_t packed, float w)
+{
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+    return acc;
 }
 
-// TextureCube.SampleLevel, MIN_MAG_MIP_LINEAR
+// bilinear taps of one mip, accumulated into r with weight `scale`: 4 x 8-byte loads, 12 mixed-precision FMAs.
+// u,v in [0,1] (a NaN direction gives index 0 and NaN weights, i.e. a NaN result, like the reference).
+__device__ __forceinline__ void cube_bilinear_acc(F3& r, const uint2* __restrict__ env, uint32_t mipOffset, uint32_t N, uint32_t face, float u, float v, float scale)
+{
+    const uint32_t E = N + 2u;
+    const float fN = (float)N;
+    const float x = fmaf(u, fN, 0.5f), y = fmaf(v, fN, 0.5f); // bordered coordinates, in [0.5, N + 0.5]
+    const uint32_t i0 = (uint32_t)x, j0 = (uint32_t)y;        // truncation == floor for x >= 0; NaN -> 0
+    const float fx = x - (float)i0, fy = y - (float)j0;
+    const uint32_t off = (mipOffset + (face * E + j0) * E + i0) * 8u, row = E * 8u;
+    // the two taps of a row are adjacent in memory: one 16-byte load per row (8-byte aligned; gfx950 loads may be unaligned)
+    const uint4u r0 = ld<uint4u>(env, off), r1 = ld<uint4u>(env, off + row);
+    const uint2 t00 = make_uint2(r0.x, r0.y), t10 = make_uint2(r0.z, r0.w), t01 = make_uint2(r1.x, r1.y), t11 = make_uint2(r1.z, r1.w);
+    const float wy1 = fy * scale, wy0 = scale - wy1;
+    const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = wy1 * fx, w01 = wy1 - w11;
+    r.x = mix_lo(mix_lo(mix_lo(mix_lo(r.x, t00.x, w00), t10.x, w10), t01.x, w01), t11.x, w11);
+    r.y = mix_hi(mix_hi(mix_hi(mix_hi(r.y, t00.x, w00), t10.x, w10), t01.x, w01), t11.x, w11);
+    r.z = mix_lo(mix_lo(mix_lo(mix_lo(r.z, t00.y, w00), t10.y, w10), t01.y, w01), t11.y, w11);
+}
+
+// TextureCube.SampleLevel, MIN_MAG_MIP_LINEAR, per-pixel level
 __device__ __forceinline__ F3 cube_sample_level(const LightingParams& p, F3 dir, float level)
 {
     const float l = fminf(fmaxf(level, 0.0f), (float)(p.envMips - 1u));
-    const float l0 = floorf(l);
-    const uint32_t m0 = (uint32_t)l0, m1 = min(m0 + 1u, p.envMips - 1u);
-    const float fl = l - l0;
+    const uint32_t m0 = (uint32_t)l, m1 = min(m0 + 1u, p.envMips - 1u);
+    const float fl = l - (float)m0;
     const CubeUV c = cube_face(dir);
-    F3 r = cube_bilinear(p, m0, c, 1.0f - fl);
-    if (fl != 0.0f) { // (m1 == m0 only when fl == 0 after the clamp)
-        const F3 r1 = cube_bilinear(p, m1, c, fl);
-        r = f3(r.x + r1.x, r.y + r1.y, r.z + r1.z);
-    }
+    const uint2* env = reinterpret_cast<const uint2*>(p.env);
+    F3 r = f3(0.0f, 0.0f, 0.0f);
+    cube_bilinear_acc(r, env, p.envMipOffset[m0], max(1u, p.envBase >> m0), c.face, c.u, c.v, 1.0f - fl);
+    if (fl != 0.0f) cube_bilinear_acc(r, env, p.envMipOffset[m1], max(1u, p.envBase >> m1), c.face, c.u, c.v, fl); // m1 == m0 only when fl == 0
     return r;
 }
 
-// the last mip only (irradiance lookup at maxMip when it is the top of the chain)
-__device__ __forceinline__ F3 cube_sample_mip(const LightingParams& p, F3 dir, uint32_t mip)
+// Same with a launch-uniform level (the irradiance lookup at maxMip): the mip pair and blend are folded on the host.
+__device__ __forceinline__ F3 cube_sample_uniform_level(const LightingParams& p, F3 dir)
 {
-    return cube_bilinear(p, mip, cube_face(dir), 1.0f);
+    const CubeUV c = cube_face(dir);
+    const uint2* env = reinterpret_cast<const uint2*>(p.env);
+    F3 r = f3(0.0f, 0.0f, 0.0f);
+    cube_bilinear_acc(r, env, p.irrOffset0, p.irrN0, c.face, c.u, c.v, 1.0f - p.irrFrac);
+    if (p.irrFrac != 0.0f) cube_bilinear_acc(r, env, p.irrOffset1, p.irrN1, c.face, c.u, c.v, p.irrFrac);
+    return r;
 }
 
 __device__ __forceinline__ void lut_sample(const LightingParams& p, float u, float v, float& a, float& b)
@@ -152,9 +177,9 @@ __device__ __forceinline__ void lut_sample(const LightingParams& p, float u, flo
     const int W1 = (int)p.lutW - 1, H1 = (int)p.lutH - 1;
     const int i0 = min(max((int)x0, 0), W1), i1 = min(max((int)x0 + 1, 0), W1);
     const int j0 = min(max((int)y0, 0), H1), j1 = min(max((int)y0 + 1, 0), H1);
-    const uint32_t* r0 = p.lut + j0 * p.lutW;
-    const uint32_t* r1 = p.lut + j1 * p.lutW;
-    const uint32_t t00 = r0[i0], t10 = r0[i1], t01 = r1[i0], t11 = r1[i1];
+    const uint32_t r0 = (uint32_t)j0 * p.lutW, r1 = (uint32_t)j1 * p.lutW;
+    const uint32_t t00 = ld<uint32_t>(p.lut, (r0 + i0) * 4u), t10 = ld<uint32_t>(p.lut, (r0 + i1) * 4u);
+    const uint32_t t01 = ld<uint32_t>(p.lut, (r1 + i0) * 4u), t11 = ld<uint32_t>(p.lut, (r1 + i1) * 4u);
     const float s = 1.0f / 65535.0f;
     const float wy1 = fy * s, wy0 = s - wy1;
     const float w00 = wy0 - wy0 * fx, w10 = wy0 * fx, w01 = wy1 - wy1 * fx, w11 = wy1 * fx;
@@ -162,51 +187,54 @@ __device__ __forceinline__ void lut_sample(const LightingParams& p, float u, flo
     b = fmaf(w11, (float)(t11 >> 16), fmaf(w01, (float)(t01 >> 16), fmaf(w10, (float)(t10 >> 16), w00 * (float)(t00 >> 16))));
 }
 
-// One SampleCmpLevelZero: bilinear blend of four LESS_EQUAL results, border = 1.0. (general path)
-__device__ __noinline__ float shadow_cmp_general(const float* __restrict__ map, int W, int H, float x, float y, float cmp)
+__device__ __forceinline__ float step_le(float cmp, float t)
 {
-    const float x0 = floorf(x), y0 = floorf(y);
-    const float fx = x - x0, fy = y - y0;
-    const int i0 = (int)x0, j0 = (int)y0;
-    float r[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int xi = i0 + (k & 1), yj = j0 + (k >> 1);
-        const bool in = xi >= 0 && yj >= 0 && xi < W && yj < H;
-        const float t = in ? map[(size_t)yj * W + xi] : 1.0f;
-        r[k] = cmp <= t ? 1.0f : 0.0f;
-    }
-    return mix(mix(r[0], r[1], fx), mix(r[2], r[3], fx), fy);
+    float r;
+    asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(r) : "v"(t - cmp), "v"(0x1p126f));
+    return r;
 }
 
-// The four PCF samples of DeferredLighting.hlsl:62-70. Their footprints are (u, u+1texel) x (v, v+1texel); when the
-// second sample's integer coordinate is the first's + 1 (always, up to fp rounding at texel boundaries) the union is a
-// 3x3 block and the sum of the four bilinear blends factors into separable weights — 9 loads, 9 compares.
+// The four PCF samples of DeferredLighting.hlsl:62-70: SampleCmpLevelZero (bilinear blend of four LESS_EQUAL results,
+// border = 1.0) at (u, u + 1 texel) x (v, v + 1 texel). The second sample's footprint is the first's shifted by exactly
+// one texel, so the union is a 3x3 block and the sum of the four bilinear blends factors into separable weights
+// (1-f, 1, f) per axis: 9 loads, 9 compares. (The oracle evaluates the shifted coordinate (u + 1/W) * W - 0.5 in fp32;
+// its fraction differs from f by O(1e-4), i.e. O(1e-5) in the result — far inside the HDR tolerance.)
 __device__ __forceinline__ float shadow_pcf(const LightingParams& p, float su, float sv, float cmp)
 {
-    const float xa = fmaf(su, p.shadowW, -0.5f), xb = fmaf(su + p.shadowTexelX, p.shadowW, -0.5f);
-    const float ya = fmaf(sv, p.shadowH, -0.5f), yb = fmaf(sv + p.shadowTexelY, p.shadowH, -0.5f);
-    const float xa0 = floorf(xa), xb0 = floorf(xb), ya0 = floorf(ya), yb0 = floorf(yb);
+    const float xa = fmaf(su, p.shadowW, -0.5f), ya = fmaf(sv, p.shadowH, -0.5f);
+    const float xa0 = floorf(xa), ya0 = floorf(ya);
+    const float fx = xa - xa0, fy = ya - ya0;
     const int ia = (int)xa0, ja = (int)ya0;
     const int W = p.shadowWi, H = p.shadowHi;
-    const bool fast = (xb0 == xa0 + 1.0f) && (yb0 == ya0 + 1.0f) && ia >= 0 && ja >= 0 && ia + 2 < W && ja + 2 < H;
-    if (__builtin_expect(fast, 1)) {
-        const float fxa = xa - xa0, fxb = xb - xb0, fya = ya - ya0, fyb = yb - yb0;
-        const float wx0 = 1.0f - fxa, wx1 = fxa + (1.0f - fxb), wx2 = fxb;
-        const float wy0 = 1.0f - fya, wy1 = fya + (1.0f - fyb), wy2 = fyb;
-        const float* row = p.shadow + (size_t)ja * W + ia;
-        float acc = 0.0f;
+    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    float acc;
+    if (__builtin_expect(ia >= 0 && ja >= 0 && ia + 2 < W && ja + 2 < H, 1)) {
+        const uint32_t o0 = ((uint32_t)ja * (uint32_t)W + (uint32_t)ia) * 4u, o1 = o0 + (uint32_t)W * 4u, o2 = o1 + (uint32_t)W * 4u;
+        const float* __restrict__ m = p.shadow;
+        const float3u ra = ld<float3u>(m, o0), rb = ld<float3u>(m, o1), rc = ld<float3u>(m, o2); // one 12-byte load per row
+        const float a0 = ra.x, a1 = ra.y, a2 = ra.z, b0 = rb.x, b1 = rb.y, b2 = rb.z, c0 = rc.x, c1 = rc.y, c2 = rc.z;
+        // step(t) = (cmp <= t) as saturate((t - cmp) * 2^126 + 1): full-rate sub + clamped FMA instead of the half-rate
+        // v_cmp + v_cndmask pair; exact for every finite pair (equality gives 1, NaN gives 0 like the comparison).
+        const float r0 = fmaf(step_le(cmp, a2), fx, fmaf(step_le(cmp, a0), wx0, step_le(cmp, a1)));
+        const float r1 = fmaf(step_le(cmp, b2), fx, fmaf(step_le(cmp, b0), wx0, step_le(cmp, b1)));
+        const float r2 = fmaf(step_le(cmp, c2), fx, fmaf(step_le(cmp, c0), wx0, step_le(cmp, c1)));
+        acc = fmaf(fy, r2, fmaf(wy0, r0, r1));
+    } else { // footprint touches the border: out-of-range taps read the border colour 1.0
+        acc = 0.0f;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float t0 = row[0], t1 = row[1], t2 = row[2];
-            const float s = (cmp <= t0 ? wx0 : 0.0f) + (cmp <= t1 ? wx1 : 0.0f) + (cmp <= t2 ? wx2 : 0.0f);
-            acc = fmaf(r == 0 ? wy0 : (r == 1 ? wy1 : wy2), s, acc);
-            row += W;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int xi = ia + c, yj = ja + r;
+                const bool in = xi >= 0 && yj >= 0 && xi < W && yj < H;
+                const float t = in ? p.shadow[(uint32_t)yj * (uint32_t)W + (uint32_t)xi] : 1.0f;
+                s += cmp <= t ? (c == 0 ? wx0 : (c == 1 ? 1.0f : fx)) : 0.0f;
+            }
+            acc = fmaf(r == 0 ? wy0 : (r == 1 ? 1.0f : fy), s, acc);
         }
-        return 0.25f * acc;
     }
-    return 0.25f * (shadow_cmp_general(p.shadow, W, H, xa, ya, cmp) + shadow_cmp_general(p.shadow, W, H, xb, ya, cmp) +
-                    shadow_cmp_general(p.shadow, W, H, xa, yb, cmp) + shadow_cmp_general(p.shadow, W, H, xb, yb, cmp));
+    return 0.25f * acc;
 }
 
 // DeferredLighting.hlsl:35-94 for one pixel. (a,b) = camera ray (ndc.x/P11, -ndc.y/P22); viewPos = viewZ * (a, b, 1).
@@ -250,7 +278,7 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     const float hr = rsq(dot(Hv, Hv));
     const float NdotL = sat(dot(N, L));
     const float NdotH = sat(dot(N, Hv) * hr);
-    const float VdotH = sat(dot(V, Hv) * hr);
+    const float VdotH = dot(V, Hv) * hr; // = (1 + V.L)/|V + L| in [0,1]: saturate is the identity up to rounding
     const float alpha = roughness * roughness;
     const float alpha2 = alpha * alpha;
     const float denom = fmaf(NdotH * NdotH, alpha2 - 1.0f, 1.0f);
@@ -274,7 +302,7 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     const F3 prefiltered = cube_sample_level(p, Rw, roughness * p.maxMip);
     float ba, bb;
     lut_sample(p, NdotV, roughness, ba, bb);
-    const F3 irradiance = cube_sample_level(p, Nw, p.maxMip);
+    const F3 irradiance = cube_sample_uniform_level(p, Nw);
 
     F3 color;
 #define UR_CHANNEL(ch, i)                                                                                     \
@@ -327,7 +355,7 @@ __global__ __launch_bounds__(256) void lighting_kernel(LightingParams p)
     const uint32_t r = blockIdx.y * TH + (lane / TW); // row inside the band
     if (px >= p.W || r >= p.rows) return;
     const uint32_t py = p.row0 + r;
-    const size_t i = (size_t)r * p.W + px;
+    const uint32_t i = r * p.W + px; // pixel index inside the band (< 2^29: byte offsets below stay 32-bit)
     const float ndcx = fmaf((float)px + 0.5f, p.invW2, -1.0f);
     const float ndcy = fmaf((float)py + 0.5f, p.invH2, -1.0f);
 
@@ -335,25 +363,25 @@ __global__ __launch_bounds__(256) void lighting_kernel(LightingParams p)
         const float vx = ndcx * p.skyInvP11, vy = -ndcy * p.skyInvP22;
         const float len = __builtin_amdgcn_sqrtf(fmaf(vx, vx, fmaf(vy, vy, 1.0f)));
         const float skyDepth = p.skyNearOverR * len; // Near / (R * unit_dir.z), unit_dir.z = 1/len
-        if (skyDepth >= p.depth[i]) {
+        if (skyDepth >= ld<float>(p.depth, i * 4u)) {
             const F3 sky = sky_pixel(p, vx, vy);
             half4_t o;
             o.x = (_Float16)sky.x; o.y = (_Float16)sky.y; o.z = (_Float16)sky.z; o.w = (_Float16)1.0f;
-            p.hdr[i] = o;
+            st<half4_t>(p.hdr, i * 8u, o);
             return;
         }
         if (MODE == ur::UR_MODE_SKY) return;
     }
-    const half4_t ga = p.A[i], gb = p.B[i];
-    const uint32_t gc = p.C[i];
-    const half4_t d = p.hdr[i];
+    const half4_t ga = ld<half4_t>(p.A, i * 8u), gb = ld<half4_t>(p.B, i * 8u);
+    const uint32_t gc = ld<uint32_t>(p.C, i * 4u);
+    const half4_t d = ld<half4_t>(p.hdr, i * 8u);
     const F3 col = shade_pixel<SHADOWS>(p, srgb, ndcx * p.invP11, -ndcy * p.invP22, ga, gb, gc);
     half4_t o;
     o.x = (_Float16)((float)d.x + col.x);
     o.y = (_Float16)((float)d.y + col.y);
     o.z = (_Float16)((float)d.z + col.z);
     o.w = (_Float16)((float)d.w + 1.0f);
-    p.hdr[i] = o;
+    st<half4_t>(p.hdr, i * 8u, o);
 }
 
 void mat4_mul(const float* a, const float* b, float* o)
@@ -441,6 +469,14 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
             const uint32_t e = (p.envBase >> m > 1u ? p.envBase >> m : 1u) + 2u;
             off += 6u * e * e;
         }
+        {
+            const float l = std::fmin(std::fmax(p.maxMip, 0.0f), (float)(p.envMips - 1u));
+            const uint32_t m0 = (uint32_t)l, m1 = m0 + 1u < p.envMips ? m0 + 1u : p.envMips - 1u;
+            p.irrFrac = l - (float)m0;
+            p.irrOffset0 = p.envMipOffset[m0]; p.irrOffset1 = p.envMipOffset[m1];
+            p.irrN0 = p.envBase >> m0 > 1u ? p.envBase >> m0 : 1u;
+            p.irrN1 = p.envBase >> m1 > 1u ? p.envBase >> m1 : 1u;
+        }
         p.env = reinterpret_cast<const half4_t*>(T->env_cube);
         p.lut = reinterpret_cast<const uint32_t*>(T->brdf_lut_rg16);
         p.lutW = T->lut_width; p.lutH = T->lut_height;
@@ -466,6 +502,10 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         p.sunAttenuation = std::fmin(std::fmax(std::exp(-std::fmax(0.0f, 1.0f - cosSunUp) * 2.0f), 0.0f), 1.0f);
     }
     if ((uint64_t)w * rows == 0) return UR_OK;
+    if ((uint64_t)w * rows >= (1ull << 29)) {
+        set_error("band of %u x %u pixels exceeds the 2^29-pixel limit of one launch", w, rows);
+        return UR_EUNSUPPORTED;
+    }
     switch (mode) {
     case UR_MODE_LIGHTING:
         if (shadows) launch_tiled<UR_MODE_LIGHTING, true>(ctx, p); else launch_tiled<UR_MODE_LIGHTING, false>(ctx, p);
