@@ -18,6 +18,7 @@
 #include "ur_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -39,6 +40,7 @@ struct LightingParams {
     float shadowStrength, shadowBias;
     float shadowW, shadowH, shadowTexelX, shadowTexelY;
     int32_t shadowWi, shadowHi;
+    uint32_t shadowFastOK; // map is at least 3x3 texels
     float maxMip;        // max(0, EnvMapMipCount-1)
     uint32_t envBase, envMips;
     uint32_t envMipOffset[16]; // in half4 texels
@@ -124,69 +126,66 @@ __device__ __forceinline__ float mix_hi(float acc, uint32_t packed, float w)
     return acc;
 }
 
-// bilinear taps of one mip, accumulated into r with weight `scale`: 4 x 8-byte loads, 12 mixed-precision FMAs.
+// ---- gathers are split into "issue the loads" and "filter" so one pixel has every independent gather in flight
+// before the BRDF math starts (the math hides their latency; no branch separates them) -----------------------------
+struct CubeTaps { uint4u r0, r1; float fx, fy; };
+
 // u,v in [0,1] (a NaN direction gives index 0 and NaN weights, i.e. a NaN result, like the reference).
-__device__ __forceinline__ void cube_bilinear_acc(F3& r, const uint2* __restrict__ env, uint32_t mipOffset, uint32_t N, uint32_t face, float u, float v, float scale)
+__device__ __forceinline__ CubeTaps cube_taps_load(const void* __restrict__ env, uint32_t mipOffset, uint32_t N, const CubeUV& c)
 {
     const uint32_t E = N + 2u;
     const float fN = (float)N;
-    const float x = fmaf(u, fN, 0.5f), y = fmaf(v, fN, 0.5f); // bordered coordinates, in [0.5, N + 0.5]
-    const uint32_t i0 = (uint32_t)x, j0 = (uint32_t)y;        // truncation == floor for x >= 0; NaN -> 0
-    const float fx = x - (float)i0, fy = y - (float)j0;
-    const uint32_t off = (mipOffset + (face * E + j0) * E + i0) * 8u, row = E * 8u;
+    const float x = fmaf(c.u, fN, 0.5f), y = fmaf(c.v, fN, 0.5f); // bordered coordinates, in [0.5, N + 0.5]
+    const uint32_t i0 = (uint32_t)x, j0 = (uint32_t)y;            // truncation == floor for x >= 0; NaN -> 0
+    CubeTaps t;
+    t.fx = x - (float)i0;
+    t.fy = y - (float)j0;
+    const uint32_t off = (mipOffset + (c.face * E + j0) * E + i0) * 8u, row = E * 8u;
     // the two taps of a row are adjacent in memory: one 16-byte load per row (8-byte aligned; gfx950 loads may be unaligned)
-    const uint4u r0 = ld<uint4u>(env, off), r1 = ld<uint4u>(env, off + row);
-    const uint2 t00 = make_uint2(r0.x, r0.y), t10 = make_uint2(r0.z, r0.w), t01 = make_uint2(r1.x, r1.y), t11 = make_uint2(r1.z, r1.w);
-    const float wy1 = fy * scale, wy0 = scale - wy1;
-    const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = wy1 * fx, w01 = wy1 - w11;
-    r.x = mix_lo(mix_lo(mix_lo(mix_lo(r.x, t00.x, w00), t10.x, w10), t01.x, w01), t11.x, w11);
-    r.y = mix_hi(mix_hi(mix_hi(mix_hi(r.y, t00.x, w00), t10.x, w10), t01.x, w01), t11.x, w11);
-    r.z = mix_lo(mix_lo(mix_lo(mix_lo(r.z, t00.y, w00), t10.y, w10), t01.y, w01), t11.y, w11);
+    t.r0 = ld<uint4u>(env, off);
+    t.r1 = ld<uint4u>(env, off + row);
+    return t;
 }
 
-// TextureCube.SampleLevel, MIN_MAG_MIP_LINEAR, per-pixel level
-__device__ __forceinline__ F3 cube_sample_level(const LightingParams& p, F3 dir, float level)
+// r += scale * bilinear(taps): 12 mixed-precision FMAs straight from the packed fp16 texels
+__device__ __forceinline__ void cube_taps_filter(F3& r, const CubeTaps& t, float scale)
 {
-    const float l = fminf(fmaxf(level, 0.0f), (float)(p.envMips - 1u));
-    const uint32_t m0 = (uint32_t)l, m1 = min(m0 + 1u, p.envMips - 1u);
-    const float fl = l - (float)m0;
-    const CubeUV c = cube_face(dir);
-    const uint2* env = reinterpret_cast<const uint2*>(p.env);
-    F3 r = f3(0.0f, 0.0f, 0.0f);
-    cube_bilinear_acc(r, env, p.envMipOffset[m0], max(1u, p.envBase >> m0), c.face, c.u, c.v, 1.0f - fl);
-    if (fl != 0.0f) cube_bilinear_acc(r, env, p.envMipOffset[m1], max(1u, p.envBase >> m1), c.face, c.u, c.v, fl); // m1 == m0 only when fl == 0
-    return r;
+    const float wy1 = t.fy * scale, wy0 = scale - wy1;
+    const float w10 = wy0 * t.fx, w00 = wy0 - w10, w11 = wy1 * t.fx, w01 = wy1 - w11;
+    r.x = mix_lo(mix_lo(mix_lo(mix_lo(r.x, t.r0.x, w00), t.r0.z, w10), t.r1.x, w01), t.r1.z, w11);
+    r.y = mix_hi(mix_hi(mix_hi(mix_hi(r.y, t.r0.x, w00), t.r0.z, w10), t.r1.x, w01), t.r1.z, w11);
+    r.z = mix_lo(mix_lo(mix_lo(mix_lo(r.z, t.r0.y, w00), t.r0.w, w10), t.r1.y, w01), t.r1.w, w11);
 }
 
-// Same with a launch-uniform level (the irradiance lookup at maxMip): the mip pair and blend are folded on the host.
-__device__ __forceinline__ F3 cube_sample_uniform_level(const LightingParams& p, F3 dir)
-{
-    const CubeUV c = cube_face(dir);
-    const uint2* env = reinterpret_cast<const uint2*>(p.env);
-    F3 r = f3(0.0f, 0.0f, 0.0f);
-    cube_bilinear_acc(r, env, p.irrOffset0, p.irrN0, c.face, c.u, c.v, 1.0f - p.irrFrac);
-    if (p.irrFrac != 0.0f) cube_bilinear_acc(r, env, p.irrOffset1, p.irrN1, c.face, c.u, c.v, p.irrFrac);
-    return r;
-}
-
-__device__ __forceinline__ void lut_sample(const LightingParams& p, float u, float v, float& a, float& b)
+struct LutTaps { uint32_t t00, t10, t01, t11; float fx, fy; };
+__device__ __forceinline__ LutTaps lut_taps_load(const LightingParams& p, float u, float v)
 {
     const float x = fmaf(u, (float)p.lutW, -0.5f), y = fmaf(v, (float)p.lutH, -0.5f);
     const float x0 = floorf(x), y0 = floorf(y);
-    const float fx = x - x0, fy = y - y0;
+    LutTaps t;
+    t.fx = x - x0;
+    t.fy = y - y0;
     const int W1 = (int)p.lutW - 1, H1 = (int)p.lutH - 1;
-    const int i0 = min(max((int)x0, 0), W1), i1 = min(max((int)x0 + 1, 0), W1);
+    const int i0 = min(max((int)x0, 0), W1), i1 = min(max((int)x0 + 1, 0), W1); // clamp addressing
     const int j0 = min(max((int)y0, 0), H1), j1 = min(max((int)y0 + 1, 0), H1);
     const uint32_t r0 = (uint32_t)j0 * p.lutW, r1 = (uint32_t)j1 * p.lutW;
-    const uint32_t t00 = ld<uint32_t>(p.lut, (r0 + i0) * 4u), t10 = ld<uint32_t>(p.lut, (r0 + i1) * 4u);
-    const uint32_t t01 = ld<uint32_t>(p.lut, (r1 + i0) * 4u), t11 = ld<uint32_t>(p.lut, (r1 + i1) * 4u);
+    t.t00 = ld<uint32_t>(p.lut, (r0 + i0) * 4u);
+    t.t10 = ld<uint32_t>(p.lut, (r0 + i1) * 4u);
+    t.t01 = ld<uint32_t>(p.lut, (r1 + i0) * 4u);
+    t.t11 = ld<uint32_t>(p.lut, (r1 + i1) * 4u);
+    return t;
+}
+__device__ __forceinline__ void lut_taps_filter(const LutTaps& t, float& a, float& b)
+{
     const float s = 1.0f / 65535.0f;
-    const float wy1 = fy * s, wy0 = s - wy1;
-    const float w00 = wy0 - wy0 * fx, w10 = wy0 * fx, w01 = wy1 - wy1 * fx, w11 = wy1 * fx;
-    a = fmaf(w11, (float)(t11 & 0xFFFFu), fmaf(w01, (float)(t01 & 0xFFFFu), fmaf(w10, (float)(t10 & 0xFFFFu), w00 * (float)(t00 & 0xFFFFu))));
-    b = fmaf(w11, (float)(t11 >> 16), fmaf(w01, (float)(t01 >> 16), fmaf(w10, (float)(t10 >> 16), w00 * (float)(t00 >> 16))));
+    const float wy1 = t.fy * s, wy0 = s - wy1;
+    const float w10 = wy0 * t.fx, w00 = wy0 - w10, w11 = wy1 * t.fx, w01 = wy1 - w11;
+    a = fmaf(w11, (float)(t.t11 & 0xFFFFu), fmaf(w01, (float)(t.t01 & 0xFFFFu), fmaf(w10, (float)(t.t10 & 0xFFFFu), w00 * (float)(t.t00 & 0xFFFFu))));
+    b = fmaf(w11, (float)(t.t11 >> 16), fmaf(w01, (float)(t.t01 >> 16), fmaf(w10, (float)(t.t10 >> 16), w00 * (float)(t.t00 >> 16))));
 }
 
+// step(t) = (cmp <= t) as saturate((t - cmp) * 2^126 + 1): a full-rate subtract + clamped FMA instead of the half-rate
+// v_cmp + v_cndmask pair; exact for every normal pair (equality gives 1, NaN gives 0 like the comparison).
 __device__ __forceinline__ float step_le(float cmp, float t)
 {
     float r;
@@ -199,40 +198,46 @@ __device__ __forceinline__ float step_le(float cmp, float t)
 // one texel, so the union is a 3x3 block and the sum of the four bilinear blends factors into separable weights
 // (1-f, 1, f) per axis: 9 loads, 9 compares. (The oracle evaluates the shifted coordinate (u + 1/W) * W - 0.5 in fp32;
 // its fraction differs from f by O(1e-4), i.e. O(1e-5) in the result — far inside the HDR tolerance.)
-__device__ __forceinline__ float shadow_pcf(const LightingParams& p, float su, float sv, float cmp)
+struct ShadowTaps { float3u ra, rb, rc; float fx, fy; int ia, ja; };
+__device__ __forceinline__ ShadowTaps shadow_taps_load(const LightingParams& p, float su, float sv)
 {
     const float xa = fmaf(su, p.shadowW, -0.5f), ya = fmaf(sv, p.shadowH, -0.5f);
     const float xa0 = floorf(xa), ya0 = floorf(ya);
-    const float fx = xa - xa0, fy = ya - ya0;
-    const int ia = (int)xa0, ja = (int)ya0;
-    const int W = p.shadowWi, H = p.shadowHi;
-    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    float acc;
-    if (__builtin_expect(ia >= 0 && ja >= 0 && ia + 2 < W && ja + 2 < H, 1)) {
-        const uint32_t o0 = ((uint32_t)ja * (uint32_t)W + (uint32_t)ia) * 4u, o1 = o0 + (uint32_t)W * 4u, o2 = o1 + (uint32_t)W * 4u;
-        const float* __restrict__ m = p.shadow;
-        const float3u ra = ld<float3u>(m, o0), rb = ld<float3u>(m, o1), rc = ld<float3u>(m, o2); // one 12-byte load per row
-        const float a0 = ra.x, a1 = ra.y, a2 = ra.z, b0 = rb.x, b1 = rb.y, b2 = rb.z, c0 = rc.x, c1 = rc.y, c2 = rc.z;
-        // step(t) = (cmp <= t) as saturate((t - cmp) * 2^126 + 1): full-rate sub + clamped FMA instead of the half-rate
-        // v_cmp + v_cndmask pair; exact for every finite pair (equality gives 1, NaN gives 0 like the comparison).
-        const float r0 = fmaf(step_le(cmp, a2), fx, fmaf(step_le(cmp, a0), wx0, step_le(cmp, a1)));
-        const float r1 = fmaf(step_le(cmp, b2), fx, fmaf(step_le(cmp, b0), wx0, step_le(cmp, b1)));
-        const float r2 = fmaf(step_le(cmp, c2), fx, fmaf(step_le(cmp, c0), wx0, step_le(cmp, c1)));
-        acc = fmaf(fy, r2, fmaf(wy0, r0, r1));
-    } else { // footprint touches the border: out-of-range taps read the border colour 1.0
-        acc = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            float s = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int xi = ia + c, yj = ja + r;
-                const bool in = xi >= 0 && yj >= 0 && xi < W && yj < H;
-                const float t = in ? p.shadow[(uint32_t)yj * (uint32_t)W + (uint32_t)xi] : 1.0f;
-                s += cmp <= t ? (c == 0 ? wx0 : (c == 1 ? 1.0f : fx)) : 0.0f;
-            }
-            acc = fmaf(r == 0 ? wy0 : (r == 1 ? 1.0f : fy), s, acc);
+    ShadowTaps t;
+    t.fx = xa - xa0;
+    t.fy = ya - ya0;
+    t.ia = (int)xa0;
+    t.ja = (int)ya0;
+    // clamped block origin: always a valid address (shadow maps narrower than 3 texels never take this path)
+    const uint32_t ic = (uint32_t)min(max(t.ia, 0), p.shadowWi - 3), jc = (uint32_t)min(max(t.ja, 0), p.shadowHi - 3);
+    const uint32_t W = (uint32_t)p.shadowWi;
+    const uint32_t o0 = (jc * W + ic) * 4u, o1 = o0 + W * 4u, o2 = o1 + W * 4u;
+    t.ra = ld<float3u>(p.shadow, o0); // one 12-byte load per row
+    t.rb = ld<float3u>(p.shadow, o1);
+    t.rc = ld<float3u>(p.shadow, o2);
+    return t;
+}
+__device__ __forceinline__ float shadow_taps_filter(const ShadowTaps& t, float cmp)
+{
+    const float wx0 = 1.0f - t.fx, wy0 = 1.0f - t.fy;
+    const float r0 = fmaf(step_le(cmp, t.ra.z), t.fx, fmaf(step_le(cmp, t.ra.x), wx0, step_le(cmp, t.ra.y)));
+    const float r1 = fmaf(step_le(cmp, t.rb.z), t.fx, fmaf(step_le(cmp, t.rb.x), wx0, step_le(cmp, t.rb.y)));
+    const float r2 = fmaf(step_le(cmp, t.rc.z), t.fx, fmaf(step_le(cmp, t.rc.x), wx0, step_le(cmp, t.rc.y)));
+    return 0.25f * fmaf(t.fy, r2, fmaf(wy0, r0, r1));
+}
+// footprint touches the border (or the map is tiny): out-of-range taps read the border colour 1.0
+__device__ __noinline__ float shadow_pcf_border(const float* __restrict__ map, int W, int H, int ia, int ja, float fx, float fy, float cmp)
+{
+    float acc = 0.0f;
+    for (int r = 0; r < 3; ++r) {
+        float s = 0.0f;
+        for (int c = 0; c < 3; ++c) {
+            const int xi = ia + c, yj = ja + r;
+            const bool in = xi >= 0 && yj >= 0 && xi < W && yj < H;
+            const float t = in ? map[(uint32_t)yj * (uint32_t)W + (uint32_t)xi] : 1.0f;
+            s += cmp <= t ? (c == 0 ? 1.0f - fx : (c == 1 ? 1.0f : fx)) : 0.0f;
         }
+        acc = fmaf(r == 0 ? 1.0f - fy : (r == 1 ? 1.0f : fy), s, acc);
     }
     return 0.25f * acc;
 }
@@ -241,21 +246,35 @@ __device__ __forceinline__ float shadow_pcf(const LightingParams& p, float su, f
 template <bool SHADOWS>
 __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* srgb, float ra, float rb, half4_t ga, half4_t gb, uint32_t gc)
 {
+    // ---- decode, view vectors ------------------------------------------------------------------------------------------
     const float nx = (float)ga.x, ny = (float)ga.y, nz = (float)ga.z;
     const float nr = rsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx))); // normalize(0) = NaN, as in the reference
     const F3 N = f3(nx * nr, ny * nr, nz * nr);
     const float viewZ = -(float)ga.w;
     const float spec0 = (float)gb.x, metallic = (float)gb.y, roughness = (float)gb.z;
-    const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
-    const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
-
     // V = normalize(-viewPos) = -sign(viewZ) * (a,b,1)/|(a,b,1)|
     const float rl = rsq(fmaf(ra, ra, fmaf(rb, rb, 1.0f)));
     const float vs = viewZ > 0.0f ? -rl : (viewZ < 0.0f ? rl : __builtin_nanf("")); // normalize(0) = NaN
     const F3 V = f3(ra * vs, rb * vs, vs);
     const F3 L = f3(p.L[0], p.L[1], p.L[2]);
+    const float NdotVraw = dot(N, V);
+    const float NdotV = sat(NdotVraw);
 
-    float shadow = 1.0f;
+    // ---- issue every gather ------------------------------------------------------------------------------------------
+    // IBL: world vectors are the view-space ones rotated by (float3x3)ViewInverse; reflect(-V, N) = 2 N (N.V) - V
+    const float t2 = 2.0f * NdotVraw;
+    const CubeUV cr = cube_face(rot(f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z)), p.R));
+    const CubeUV cn = cube_face(rot(N, p.R));
+    const float lvl = fminf(fmaxf(roughness * p.maxMip, 0.0f), (float)(p.envMips - 1u));
+    const uint32_t m0 = (uint32_t)lvl, m1 = min(m0 + 1u, p.envMips - 1u);
+    const float fl = lvl - (float)m0; // m1 == m0 only when fl == 0: the second mip then carries weight 0
+    const CubeTaps pre0 = cube_taps_load(p.env, p.envMipOffset[m0], max(1u, p.envBase >> m0), cr);
+    const CubeTaps pre1 = cube_taps_load(p.env, p.envMipOffset[m1], max(1u, p.envBase >> m1), cr);
+    const CubeTaps irr0 = cube_taps_load(p.env, p.irrOffset0, p.irrN0, cn);
+    const LutTaps lut = lut_taps_load(p, NdotV, roughness);
+    float su = 0.0f, sv = 0.0f, cmp = 0.0f;
+    bool lit = false;
+    ShadowTaps sh{};
     if (SHADOWS) {
         // shadow clip = viewZ * ((a,b,1) * M3) + M[3]
         const float qx = fmaf(rb, p.SQ[4], fmaf(ra, p.SQ[0], p.SQ[8]));
@@ -263,17 +282,16 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
         const float qz = fmaf(rb, p.SQ[6], fmaf(ra, p.SQ[2], p.SQ[10]));
         const float qw = fmaf(rb, p.SQ[7], fmaf(ra, p.SQ[3], p.SQ[11]));
         const float iw = rcp(fmaf(viewZ, qw, p.ST[3]));
-        const float su = fmaf(fmaf(viewZ, qx, p.ST[0]) * iw, 0.5f, 0.5f);
-        const float sv = fmaf(fmaf(viewZ, qy, p.ST[1]) * iw, -0.5f, 0.5f);
-        if (su >= 0.0f && sv >= 0.0f && su <= 1.0f && sv <= 1.0f) {
-            const float cmp = fmaf(viewZ, qz, p.ST[2]) * iw - p.shadowBias;
-            shadow = mix(1.0f, shadow_pcf(p, su, sv, cmp), p.shadowStrength);
-        }
+        su = fmaf(fmaf(viewZ, qx, p.ST[0]) * iw, 0.5f, 0.5f);
+        sv = fmaf(fmaf(viewZ, qy, p.ST[1]) * iw, -0.5f, 0.5f);
+        cmp = fmaf(viewZ, qz, p.ST[2]) * iw - p.shadowBias;
+        lit = su >= 0.0f && sv >= 0.0f && su <= 1.0f && sv <= 1.0f;
+        if (p.shadowFastOK) sh = shadow_taps_load(p, su, sv); // uniform branch
     }
+    const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
 
-    // EvaluatePBR, PBRCommon.hlsl:24-48
-    const float NdotVraw = dot(N, V);
-    const float NdotV = sat(NdotVraw);
+    // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) --------------------------------------------
+    const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
     F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
     const float hr = rsq(dot(Hv, Hv));
     const float NdotL = sat(dot(N, L));
@@ -293,22 +311,33 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     const float om2 = om * om;
     const float p5 = om2 * om2 * om;
     const float kdm = 1.0f - metallic;
-    const float sh = shadow * NdotL;
 
-    // IBL: world vectors are the view-space ones rotated by (float3x3)ViewInverse; reflect(-V, N) = 2 N (N.V) - V
-    const float t2 = 2.0f * NdotVraw;
-    const F3 Rw = rot(f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z)), p.R);
-    const F3 Nw = rot(N, p.R);
-    const F3 prefiltered = cube_sample_level(p, Rw, roughness * p.maxMip);
+    // ---- filter ---------------------------------------------------------------------------------------------------------------
+    float shadow = 1.0f;
+    if (SHADOWS) {
+        const bool fast = p.shadowFastOK && sh.ia >= 0 && sh.ja >= 0 && sh.ia + 2 < p.shadowWi && sh.ja + 2 < p.shadowHi;
+        float s = shadow_taps_filter(sh, cmp);
+        if (__builtin_expect(lit && !fast, 0)) {
+            const float xa = fmaf(su, p.shadowW, -0.5f), ya = fmaf(sv, p.shadowH, -0.5f);
+            const float xa0 = floorf(xa), ya0 = floorf(ya);
+            s = shadow_pcf_border(p.shadow, p.shadowWi, p.shadowHi, (int)xa0, (int)ya0, xa - xa0, ya - ya0, cmp);
+        }
+        shadow = lit ? mix(1.0f, s, p.shadowStrength) : 1.0f;
+    }
+    const float sh_l = shadow * NdotL;
+    F3 prefiltered = f3(0.0f, 0.0f, 0.0f), irradiance = f3(0.0f, 0.0f, 0.0f);
+    cube_taps_filter(prefiltered, pre0, 1.0f - fl);
+    cube_taps_filter(prefiltered, pre1, fl);
+    cube_taps_filter(irradiance, irr0, 1.0f - p.irrFrac);
+    if (p.irrFrac != 0.0f) cube_taps_filter(irradiance, cube_taps_load(p.env, p.irrOffset1, p.irrN1, cn), p.irrFrac); // uniform
     float ba, bb;
-    lut_sample(p, NdotV, roughness, ba, bb);
-    const F3 irradiance = cube_sample_uniform_level(p, Nw);
+    lut_taps_filter(lut, ba, bb);
 
     F3 color;
 #define UR_CHANNEL(ch, i)                                                                                     \
     {                                                                                                         \
         const float F = fmaf(1.0f - F0.ch, p5, F0.ch);                                                        \
-        const float direct = fmaf((1.0f - F) * kdm, albedo.ch, sc * F) * (p.lightRGB[i] * sh);                \
+        const float direct = fmaf((1.0f - F) * kdm, albedo.ch, sc * F) * (p.lightRGB[i] * sh_l);              \
         color.ch = fmaf(irradiance.ch * albedo.ch, kdm, fmaf(prefiltered.ch, fmaf(F0.ch, ba, bb), direct));   \
     }
     UR_CHANNEL(x, 0)
@@ -341,8 +370,8 @@ __device__ __forceinline__ F3 sky_pixel(const LightingParams& p, float vx, float
 }
 
 // A workgroup is 4 waves; a wave covers TW x TH pixels; the four waves sit side by side in x.
-template <int MODE, bool SHADOWS, int TW>
-__global__ __launch_bounds__(256) void lighting_kernel(LightingParams p)
+template <int MODE, bool SHADOWS, int TW, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
 {
     constexpr int TH = 64 / TW;
     __shared__ float srgb[256];
@@ -384,6 +413,84 @@ __global__ __launch_bounds__(256) void lighting_kernel(LightingParams p)
     st<half4_t>(p.hdr, i * 8u, o);
 }
 
+// Persistent form of the same kernel: workgroups loop over 64x4-pixel tiles (stride gridDim.x) and issue the NEXT
+// tile's streaming G-buffer loads before shading the current one, so HBM latency hides under ~500 VALU instructions
+// instead of relying on occupancy alone; the sRGB table is staged into LDS once per workgroup instead of once per tile.
+struct PixelIn {
+    half4_t a, b, d;
+    uint32_t c;
+    float depth;
+    uint32_t i, px, py;
+    bool valid;
+};
+
+template <int MODE, int TW>
+__device__ __forceinline__ PixelIn fetch_pixel(const LightingParams& p, uint32_t tile, uint32_t tilesX, uint32_t lane, uint32_t wave)
+{
+    constexpr int TH = 64 / TW;
+    PixelIn q;
+    const uint32_t ty = tile / tilesX, tx = tile - ty * tilesX; // uniform: scalar ALU
+    q.px = (tx * 4u + wave) * TW + (lane % TW);
+    const uint32_t r = ty * TH + (lane / TW);
+    q.valid = q.px < p.W && r < p.rows;
+    q.py = p.row0 + r;
+    q.i = r * p.W + q.px;
+    const uint32_t i = q.valid ? q.i : 0u;
+    if (MODE != ur::UR_MODE_LIGHTING) q.depth = ld<float>(p.depth, i * 4u);
+    q.a = ld<half4_t>(p.A, i * 8u);
+    q.b = ld<half4_t>(p.B, i * 8u);
+    q.c = ld<uint32_t>(p.C, i * 4u);
+    q.d = ld<half4_t>(p.hdr, i * 8u);
+    return q;
+}
+
+template <int MODE, bool SHADOWS, int TW>
+__global__ __launch_bounds__(256) void lighting_kernel_persistent(LightingParams p, uint32_t tilesX, uint32_t numTiles)
+{
+    static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the simple kernel");
+    __shared__ float srgb[256];
+    srgb[threadIdx.x] = p.srgb[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t tile = blockIdx.x;
+    if (tile >= numTiles) return;
+    PixelIn cur = fetch_pixel<MODE, TW>(p, tile, tilesX, lane, wave);
+    for (;;) {
+        const uint32_t next = tile + gridDim.x;
+        const bool more = next < numTiles; // uniform
+        PixelIn nxt = cur;
+        if (more) nxt = fetch_pixel<MODE, TW>(p, next, tilesX, lane, wave);
+        if (cur.valid) {
+            const float ndcx = fmaf((float)cur.px + 0.5f, p.invW2, -1.0f);
+            const float ndcy = fmaf((float)cur.py + 0.5f, p.invH2, -1.0f);
+            bool sky = false;
+            if (MODE == ur::UR_MODE_FUSED) {
+                const float vx = ndcx * p.skyInvP11, vy = -ndcy * p.skyInvP22;
+                const float len = __builtin_amdgcn_sqrtf(fmaf(vx, vx, fmaf(vy, vy, 1.0f)));
+                sky = p.skyNearOverR * len >= cur.depth;
+                if (sky) {
+                    const F3 c = sky_pixel(p, vx, vy);
+                    half4_t o;
+                    o.x = (_Float16)c.x; o.y = (_Float16)c.y; o.z = (_Float16)c.z; o.w = (_Float16)1.0f;
+                    st<half4_t>(p.hdr, cur.i * 8u, o);
+                }
+            }
+            if (!sky) {
+                const F3 col = shade_pixel<SHADOWS>(p, srgb, ndcx * p.invP11, -ndcy * p.invP22, cur.a, cur.b, cur.c);
+                half4_t o;
+                o.x = (_Float16)((float)cur.d.x + col.x);
+                o.y = (_Float16)((float)cur.d.y + col.y);
+                o.z = (_Float16)((float)cur.d.z + col.z);
+                o.w = (_Float16)((float)cur.d.w + 1.0f);
+                st<half4_t>(p.hdr, cur.i * 8u, o);
+            }
+        }
+        if (!more) break;
+        cur = nxt;
+        tile = next;
+    }
+}
+
 void mat4_mul(const float* a, const float* b, float* o)
 {
     for (int i = 0; i < 4; ++i)
@@ -394,12 +501,39 @@ void mat4_mul(const float* a, const float* b, float* o)
         }
 }
 
+int env_int(const char* name, int dflt)
+{
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
+template <int MODE, bool SHADOWS, int TW>
+void launch_tile_shape(ur_ctx* ctx, const LightingParams& p)
+{
+    const uint32_t tilesX = (p.W + 4 * TW - 1) / (4 * TW), tilesY = (p.rows + (64 / TW) - 1) / (64 / TW);
+    if constexpr (MODE != ur::UR_MODE_SKY) {
+        static const int bpc = env_int("UR_LIGHTING_PERSISTENT", 0); // 0 = one workgroup per tile; N = N persistent workgroups per CU
+        const uint32_t numTiles = tilesX * tilesY;
+        if (bpc > 0 && numTiles > (uint32_t)(ctx->cu_count * bpc)) {
+            hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
+            return;
+        }
+    }
+    // register budget: 6 waves/SIMD (80 VGPRs) holds every gather of a pixel in flight without spilling
+    hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
+}
+
 template <int MODE, bool SHADOWS>
 void launch_tiled(ur_ctx* ctx, const LightingParams& p)
 {
-    constexpr int TW = 16; // 16 x 4 pixels per wave: 128-byte G-buffer row segments, compact gather footprints
-    const dim3 grid((p.W + 4 * TW - 1) / (4 * TW), (p.rows + (64 / TW) - 1) / (64 / TW));
-    hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW>), grid, dim3(256), 0, ctx->stream, p);
+    // pixels per wave = TW x (64/TW). 16 x 4: 128-byte G-buffer row segments and compact gather footprints.
+    static const int tw = env_int("UR_LIGHTING_TW", 16);
+    switch (tw) {
+    case 8: launch_tile_shape<MODE, SHADOWS, 8>(ctx, p); break;
+    case 32: launch_tile_shape<MODE, SHADOWS, 32>(ctx, p); break;
+    case 64: launch_tile_shape<MODE, SHADOWS, 64>(ctx, p); break;
+    default: launch_tile_shape<MODE, SHADOWS, 16>(ctx, p); break;
+    }
 }
 
 } // namespace
@@ -452,6 +586,7 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         p.shadowTexelX = 1.0f / S->ShadowMapSize[0]; p.shadowTexelY = 1.0f / S->ShadowMapSize[1];
         p.shadow = T->shadow_map;
         shadows = p.shadowStrength > 0.0f;
+        p.shadowFastOK = (p.shadowWi >= 3 && p.shadowHi >= 3) ? 1u : 0u;
         if (shadows && (p.shadow == nullptr || p.shadowWi <= 0 || p.shadowHi <= 0)) {
             set_error("ShadowStrength > 0 but no shadow map / ShadowMapSize");
             return UR_EINVAL;
