@@ -45,6 +45,8 @@ typedef struct ur_frame_resources {
 #define UR_FRAME_GPU_TIMING 0x40u
 #define UR_FRAME_GRAPH_DUMP 0x80u
 #define UR_FRAME_BARRIER_LOGS 0x100u
+#define UR_FRAME_ASYNC_COMPUTE 0x200u /* GPU Culling + Build HZB on a second HIP stream, overlapping Lighting/Sky */
+#define UR_FRAME_ASYNC_NO_JOIN 0x400u /* with ASYNC_COMPUTE: do not end the frame with a main<-async join; the caller calls ur_frame_join_async() */
 #define UR_FRAME_DEFAULT (UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY)
 
 ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size);
@@ -54,9 +56,11 @@ void ur_frame_destroy(ur_frame* f);
  * from the resources and from whether last frame built an HZB (bHZBReady). */
 int ur_frame_render(ur_frame* f, const ur_frame_resources* res, const uint32_t* culling_constants, const ur_scene_constants* scene,
                     const ur_sky_constants* sky, uint32_t option_flags);
+/* Main stream waits for everything the async-compute stream has been given so far (see UR_FRAME_ASYNC_NO_JOIN). */
+void ur_frame_join_async(ur_frame* f);
 int ur_frame_hzb_ready(const ur_frame* f);
 void ur_frame_reset_hzb(ur_frame* f);
-/* Last execution: one line per pass "name|culled(0/1)|transitions". Returns bytes needed (incl. NUL). */
+/* Last execution: one line per pass "name|culled(0/1)|transitions|async(0/1)|cross-stream waits". Returns bytes needed (incl. NUL). */
 uint32_t ur_frame_report(const ur_frame* f, char* buf, uint32_t cap);
 /* Sliding-window GPU timing (FRenderGraph::GetGpuTimingStats): "name|avg_ms|min_ms|max_ms|samples" lines. */
 uint32_t ur_rg_timing_stats(char* buf, uint32_t cap);

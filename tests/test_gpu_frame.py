@@ -79,6 +79,19 @@ def test_frame_passes_and_parity(hotpath, oracle):
     # ---- indirect draw off: the culling pass declares nothing and is culled by the graph
     render(lib.UR_FRAME_DEFAULT & ~lib.UR_FRAME_INDIRECT_DRAW, to_device(g.hdr))
     assert frame.report()[0] == ("GPU Culling", True, 0)
+    # ---- async compute: GPU Culling + Build HZB on the second stream give the same words / HZB / HDR
+    frame.reset_hzb()
+    d_hzb.zero_()
+    for k in range(3):
+        d_args.copy_(to_device(args0)); d_stats.zero_()
+        hdr3 = to_device(g.hdr)
+        render(lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY | lib.UR_FRAME_ASYNC_COMPUTE, hdr3)
+        lanes = {n: a for n, a, _ in frame.report_async()}
+        assert lanes["GPU Culling"] and lanes["Build HZB"] and not lanes["Lighting"]
+        assert torch.equal(hdr3, hdr1)
+        assert np.array_equal(d_hzb.cpu().numpy().view(np.uint32), ref_hzb.view(np.uint32))
+        want = ref_args if k == 0 else ref_args2  # first frame after the reset has no HZB yet
+        assert np.array_equal(d_args.cpu().numpy().view(np.uint32), want)
     # ---- GPU timing: event pairs per pass, harvested when the slot comes round again
     for _ in range(8):
         render(lib.UR_FRAME_DEFAULT | lib.UR_FRAME_GPU_TIMING, to_device(g.hdr))

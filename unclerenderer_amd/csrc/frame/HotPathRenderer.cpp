@@ -2,6 +2,8 @@
 
 #include "HotPathRenderer.h"
 
+#include <hip/hip_runtime.h>
+
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -54,6 +56,9 @@ int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Re
         if (Data.bEnabled) {
             if (bUseHZBOcclusion) Builder.ReadTexture(HZBHandle, RG_STATE_NON_PIXEL_SHADER_RESOURCE);
             Builder.KeepAlive();
+            // Neither visibility pass shares a resource with Lighting/Sky inside a frame (the cull reads LAST frame's
+            // HZB), so both can run beside the VALU-bound lighting kernel on the second stream.
+            if (Options.bAsyncCompute) Builder.AsyncCompute();
         }
     }, [this, &Res](const FGpuCullingPassData& Data, FHIPCommandContext& Cmd)
     {
@@ -79,6 +84,7 @@ int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Re
             Data.SourceHeight = Res.Height;
             Builder.ReadTexture(DepthHandle, RG_STATE_NON_PIXEL_SHADER_RESOURCE);
             Builder.WriteTexture(HZBHandle, RG_STATE_UNORDERED_ACCESS);
+            if (Options.bAsyncCompute) Builder.AsyncCompute();
         }, [this, &Res](const FHZBPassData& Data, FHIPCommandContext& Cmd)
         {
             if (Data.MipCount == 0) return;
@@ -160,6 +166,9 @@ struct ur_frame
     FHIPCommandContext Cmd;
     FHotPathRenderer Renderer;
     FHotPathResources Res;
+    hipStream_t AsyncStream = nullptr;
+    ur_ctx* AsyncCtx = nullptr;
+    int DeviceIndex = 0;
     ur_frame(ur_ctx* Ctx, hipStream_t Stream, uint32 Frames, int Rank, int World) : Cmd(Ctx, Stream, Frames, Rank, World), Renderer(&Device) {}
 };
 
@@ -171,7 +180,14 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
     return new ur_frame(ctx, static_cast<hipStream_t>(stream), frames_in_flight, rank, world_size);
 }
 
-void ur_frame_destroy(ur_frame* f) { delete f; }
+void ur_frame_destroy(ur_frame* f)
+{
+    if (!f) return;
+    if (f->AsyncStream) (void)hipStreamSynchronize(f->AsyncStream);
+    if (f->AsyncCtx) ur_destroy(f->AsyncCtx);
+    if (f->AsyncStream) (void)hipStreamDestroy(f->AsyncStream);
+    delete f;
+}
 
 int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* culling_constants, const ur_scene_constants* scene,
                     const ur_sky_constants* sky, uint32_t flags)
@@ -208,13 +224,23 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     O.bRenderShadows = (flags & UR_FRAME_SHADOWS) != 0;
     O.bSkyEnabled = (flags & UR_FRAME_SKY) != 0;
     O.bFuseLightingAndSky = (flags & UR_FRAME_FUSE_LIGHTING_SKY) != 0;
+    O.bAsyncCompute = (flags & UR_FRAME_ASYNC_COMPUTE) != 0;
+    if (O.bAsyncCompute && !f->AsyncCtx) { // second stream + a context bound to it, created on first use
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithPriority(&f->AsyncStream, hipStreamNonBlocking, -1) != hipSuccess) return UR_EHIP; // high priority: its short kernels slot in beside the lighting kernel
+        f->AsyncCtx = ur_create(dev, f->AsyncStream);
+        if (!f->AsyncCtx) return UR_EHIP;
+        f->Cmd.SetAsyncCompute(f->AsyncCtx, f->AsyncStream);
+    }
     O.bGpuTiming = (flags & UR_FRAME_GPU_TIMING) != 0;
     O.bGraphDump = (flags & UR_FRAME_GRAPH_DUMP) != 0;
     O.bBarrierLogs = (flags & UR_FRAME_BARRIER_LOGS) != 0;
+    f->Cmd.SetJoinAsyncAtEnd((flags & UR_FRAME_ASYNC_NO_JOIN) == 0);
     f->Cmd.BeginFrame();
     return f->Renderer.RenderFrame(f->Cmd, R, K, O);
 }
 
+void ur_frame_join_async(ur_frame* f) { if (f) f->Cmd.JoinAsyncCompute(); }
 int ur_frame_hzb_ready(const ur_frame* f) { return f && f->Renderer.IsHZBReady() ? 1 : 0; }
 void ur_frame_reset_hzb(ur_frame* f) { if (f) f->Renderer.ResetHZB(); }
 
@@ -232,7 +258,8 @@ uint32_t ur_frame_report(const ur_frame* f, char* buf, uint32_t cap)
 {
     std::ostringstream s;
     if (f)
-        for (const auto& p : f->Renderer.GetLastReport()) s << p.Name << '|' << (p.bCulled ? 1 : 0) << '|' << p.Transitions << '\n';
+        for (const auto& p : f->Renderer.GetLastReport())
+            s << p.Name << '|' << (p.bCulled ? 1 : 0) << '|' << p.Transitions << '|' << (p.bAsync ? 1 : 0) << '|' << p.CrossStreamWaits << '\n';
     return copy_out(s.str(), buf, cap);
 }
 

@@ -63,6 +63,7 @@ struct FHotPathOptions
     bool bRenderShadows = true;
     bool bSkyEnabled = true;
     bool bFuseLightingAndSky = false; // MI355X fast path: one pass, same result as Lighting followed by Sky
+    bool bAsyncCompute = false;       // MI355X: GPU Culling + Build HZB on the async-compute stream, overlapping Lighting
     bool bGpuTiming = false;
     bool bGraphDump = false;
     bool bBarrierLogs = false;

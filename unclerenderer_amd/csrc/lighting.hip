@@ -40,7 +40,6 @@ struct LightingParams {
     float shadowStrength, shadowBias;
     float shadowW, shadowH, shadowTexelX, shadowTexelY;
     int32_t shadowWi, shadowHi;
-    uint32_t shadowFastOK; // map is at least 3x3 texels
     float maxMip;        // max(0, EnvMapMipCount-1)
     uint32_t envBase, envMips;
     uint32_t envMipOffset[16]; // in half4 texels
@@ -125,6 +124,19 @@ __device__ __forceinline__ float mix_hi(float acc, uint32_t packed, float w)
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
     return acc;
 }
+// the same without an addend (first tap of a sum: no zero-initialised accumulator register)
+__device__ __forceinline__ float mul_lo(uint32_t packed, float w)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(w));
+    return r;
+}
+__device__ __forceinline__ float mul_hi(uint32_t packed, float w)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(w));
+    return r;
+}
 
 // ---- gathers are split into "issue the loads" and "filter" so one pixel has every independent gather in flight
 // before the BRDF math starts (the math hides their latency; no branch separates them) -----------------------------
@@ -147,14 +159,18 @@ __device__ __forceinline__ CubeTaps cube_taps_load(const void* __restrict__ env,
     return t;
 }
 
-// r += scale * bilinear(taps): 12 mixed-precision FMAs straight from the packed fp16 texels
+// scale * bilinear(taps) [+ r when ACC]: 12 mixed-precision FMAs straight from the packed fp16 texels
+template <bool ACC>
 __device__ __forceinline__ void cube_taps_filter(F3& r, const CubeTaps& t, float scale)
 {
     const float wy1 = t.fy * scale, wy0 = scale - wy1;
     const float w10 = wy0 * t.fx, w00 = wy0 - w10, w11 = wy1 * t.fx, w01 = wy1 - w11;
-    r.x = mix_lo(mix_lo(mix_lo(mix_lo(r.x, t.r0.x, w00), t.r0.z, w10), t.r1.x, w01), t.r1.z, w11);
-    r.y = mix_hi(mix_hi(mix_hi(mix_hi(r.y, t.r0.x, w00), t.r0.z, w10), t.r1.x, w01), t.r1.z, w11);
-    r.z = mix_lo(mix_lo(mix_lo(mix_lo(r.z, t.r0.y, w00), t.r0.w, w10), t.r1.y, w01), t.r1.w, w11);
+    const float x0 = ACC ? mix_lo(r.x, t.r0.x, w00) : mul_lo(t.r0.x, w00);
+    const float y0 = ACC ? mix_hi(r.y, t.r0.x, w00) : mul_hi(t.r0.x, w00);
+    const float z0 = ACC ? mix_lo(r.z, t.r0.y, w00) : mul_lo(t.r0.y, w00);
+    r.x = mix_lo(mix_lo(mix_lo(x0, t.r0.z, w10), t.r1.x, w01), t.r1.z, w11);
+    r.y = mix_hi(mix_hi(mix_hi(y0, t.r0.z, w10), t.r1.x, w01), t.r1.z, w11);
+    r.z = mix_lo(mix_lo(mix_lo(z0, t.r0.w, w10), t.r1.y, w01), t.r1.w, w11);
 }
 
 struct LutTaps { uint32_t t00, t10, t01, t11; float fx, fy; };
@@ -208,7 +224,7 @@ __device__ __forceinline__ ShadowTaps shadow_taps_load(const LightingParams& p, 
     t.fy = ya - ya0;
     t.ia = (int)xa0;
     t.ja = (int)ya0;
-    // clamped block origin: always a valid address (shadow maps narrower than 3 texels never take this path)
+    // clamped block origin: always a valid address (the host rejects shadow maps smaller than 3x3)
     const uint32_t ic = (uint32_t)min(max(t.ia, 0), p.shadowWi - 3), jc = (uint32_t)min(max(t.ja, 0), p.shadowHi - 3);
     const uint32_t W = (uint32_t)p.shadowWi;
     const uint32_t o0 = (jc * W + ic) * 4u, o1 = o0 + W * 4u, o2 = o1 + W * 4u;
@@ -274,7 +290,7 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     const LutTaps lut = lut_taps_load(p, NdotV, roughness);
     float su = 0.0f, sv = 0.0f, cmp = 0.0f;
     bool lit = false;
-    ShadowTaps sh{};
+    ShadowTaps sh;
     if (SHADOWS) {
         // shadow clip = viewZ * ((a,b,1) * M3) + M[3]
         const float qx = fmaf(rb, p.SQ[4], fmaf(ra, p.SQ[0], p.SQ[8]));
@@ -286,7 +302,7 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
         sv = fmaf(fmaf(viewZ, qy, p.ST[1]) * iw, -0.5f, 0.5f);
         cmp = fmaf(viewZ, qz, p.ST[2]) * iw - p.shadowBias;
         lit = su >= 0.0f && sv >= 0.0f && su <= 1.0f && sv <= 1.0f;
-        if (p.shadowFastOK) sh = shadow_taps_load(p, su, sv); // uniform branch
+        sh = shadow_taps_load(p, su, sv);
     }
     const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
 
@@ -315,7 +331,7 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     // ---- filter ---------------------------------------------------------------------------------------------------------------
     float shadow = 1.0f;
     if (SHADOWS) {
-        const bool fast = p.shadowFastOK && sh.ia >= 0 && sh.ja >= 0 && sh.ia + 2 < p.shadowWi && sh.ja + 2 < p.shadowHi;
+        const bool fast = sh.ia >= 0 && sh.ja >= 0 && sh.ia + 2 < p.shadowWi && sh.ja + 2 < p.shadowHi;
         float s = shadow_taps_filter(sh, cmp);
         if (__builtin_expect(lit && !fast, 0)) {
             const float xa = fmaf(su, p.shadowW, -0.5f), ya = fmaf(sv, p.shadowH, -0.5f);
@@ -325,11 +341,11 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
         shadow = lit ? mix(1.0f, s, p.shadowStrength) : 1.0f;
     }
     const float sh_l = shadow * NdotL;
-    F3 prefiltered = f3(0.0f, 0.0f, 0.0f), irradiance = f3(0.0f, 0.0f, 0.0f);
-    cube_taps_filter(prefiltered, pre0, 1.0f - fl);
-    cube_taps_filter(prefiltered, pre1, fl);
-    cube_taps_filter(irradiance, irr0, 1.0f - p.irrFrac);
-    if (p.irrFrac != 0.0f) cube_taps_filter(irradiance, cube_taps_load(p.env, p.irrOffset1, p.irrN1, cn), p.irrFrac); // uniform
+    F3 prefiltered, irradiance;
+    cube_taps_filter<false>(prefiltered, pre0, 1.0f - fl);
+    cube_taps_filter<true>(prefiltered, pre1, fl);
+    cube_taps_filter<false>(irradiance, irr0, 1.0f - p.irrFrac);
+    if (p.irrFrac != 0.0f) cube_taps_filter<true>(irradiance, cube_taps_load(p.env, p.irrOffset1, p.irrN1, cn), p.irrFrac); // uniform
     float ba, bb;
     lut_taps_filter(lut, ba, bb);
 
@@ -519,8 +535,10 @@ void launch_tile_shape(ur_ctx* ctx, const LightingParams& p)
             return;
         }
     }
-    // register budget: 6 waves/SIMD (80 VGPRs) holds every gather of a pixel in flight without spilling
-    hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
+    // register budget: waves/SIMD the kernel is compiled for (6 -> 80 VGPRs, 4 -> no cap)
+    static const int waves = env_int("UR_LIGHTING_WAVES", 4); // measured: 86 VGPRs without a cap beats an 80-VGPR build that spills
+    if (waves >= 6) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 4>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
 }
 
 template <int MODE, bool SHADOWS>
@@ -586,7 +604,10 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         p.shadowTexelX = 1.0f / S->ShadowMapSize[0]; p.shadowTexelY = 1.0f / S->ShadowMapSize[1];
         p.shadow = T->shadow_map;
         shadows = p.shadowStrength > 0.0f;
-        p.shadowFastOK = (p.shadowWi >= 3 && p.shadowHi >= 3) ? 1u : 0u;
+        if (shadows && (p.shadowWi < 3 || p.shadowHi < 3)) {
+            set_error("shadow maps smaller than 3x3 texels are not supported");
+            return UR_EUNSUPPORTED;
+        }
         if (shadows && (p.shadow == nullptr || p.shadowWi <= 0 || p.shadowHi <= 0)) {
             set_error("ShadowStrength > 0 but no shadow map / ShadowMapSize");
             return UR_EINVAL;

@@ -41,8 +41,25 @@ struct FTimingSample
     double Milliseconds = 0.0;
 };
 
+// Events used for cross-stream ordering, recycled per frame slot (a slot is reused only after FrameCount frames).
+struct FSyncEvents
+{
+    std::vector<hipEvent_t> Events;
+    uint32 Used = 0;
+    hipEvent_t Next()
+    {
+        if (Used == Events.size()) {
+            hipEvent_t E = nullptr;
+            if (hipEventCreateWithFlags(&E, hipEventDisableTiming) != hipSuccess) return nullptr;
+            Events.push_back(E);
+        }
+        return Events[Used++];
+    }
+};
+
 struct FGlobals
 {
+    std::unordered_map<uint32, FSyncEvents> SyncEvents;
     std::vector<FPooledTexture> TexturePool;
     std::unordered_map<uint32, FSlotTimings> SlotTimings;
     std::unordered_map<std::string, std::deque<FTimingSample>> Samples;
@@ -156,6 +173,13 @@ void FHIPDevice::Free(FRGResourcePtr Ptr)
     if (Ptr) (void)hipFree(Ptr);
 }
 
+void FHIPCommandContext::JoinAsyncCompute()
+{
+    if (!HasAsyncCompute()) return;
+    if (!JoinEvent && hipEventCreateWithFlags(&JoinEvent, hipEventDisableTiming) != hipSuccess) return;
+    if (hipEventRecord(JoinEvent, AsyncStream) == hipSuccess) (void)hipStreamWaitEvent(Stream, JoinEvent, 0);
+}
+
 FRenderGraph::FRenderGraph() = default;
 
 FRenderGraph::~FRenderGraph()
@@ -250,6 +274,11 @@ FRGResourceHandle FRGPassBuilder::WriteTexture(const FRGResourceHandle& Handle, 
 void FRGPassBuilder::KeepAlive()
 {
     if (Pass) static_cast<FRenderGraph::FPass*>(Pass)->bForceExecute = true;
+}
+
+void FRGPassBuilder::AsyncCompute()
+{
+    if (Pass) static_cast<FRenderGraph::FPass*>(Pass)->bAsync = true;
 }
 
 bool FRenderGraph::AcquireTransient(FTexture& Texture, uint32 InitialState)
@@ -366,6 +395,22 @@ void FRenderGraph::Execute(FHIPCommandContext& Cmd)
         else Timings->Used = 0;
     }
 
+    // ---- async compute: fork the async stream from the main stream; per-resource last-access events order the two
+    bool bAnyAsync = false;
+    for (size_t P = 0; P < NumPass; ++P) bAnyAsync = bAnyAsync || (PassLive[P] && Passes[P].bAsync);
+    bAnyAsync = bAnyAsync && Cmd.HasAsyncCompute();
+    FSyncEvents* Sync = nullptr;
+    struct FAccess { hipEvent_t LastWrite = nullptr; int LastWriteLane = -1; hipEvent_t LastRead[2] = {nullptr, nullptr}; };
+    std::vector<FAccess> Access;
+    if (bAnyAsync) {
+        Sync = &G().SyncEvents[Slot];
+        Sync->Used = 0;
+        Access.resize(NumTex);
+        hipEvent_t Fork = Sync->Next();
+        if (Fork && hipEventRecord(Fork, Cmd.GetMainStream()) == hipSuccess) (void)hipStreamWaitEvent(Cmd.GetAsyncStream(), Fork, 0);
+        else bAnyAsync = false;
+    }
+
     for (size_t P = 0; P < NumPass; ++P) {
         FPass& Pass = Passes[P];
         FPassReport R;
@@ -374,6 +419,22 @@ void FRenderGraph::Execute(FHIPCommandContext& Cmd)
         if (R.bCulled) {
             Report.push_back(std::move(R));
             continue;
+        }
+        const int Lane = (bAnyAsync && Pass.bAsync) ? 1 : 0;
+        R.bAsync = Lane == 1;
+        Cmd.SetAsyncLane(Lane == 1);
+        if (bAnyAsync) { // hazards against the OTHER stream: RAW (we read, they wrote), WAW / WAR (we write, they wrote / read)
+            for (const FUsage& U : Pass.Usages) {
+                FAccess& A = Access[U.Resource];
+                if (A.LastWrite && A.LastWriteLane != Lane) {
+                    (void)hipStreamWaitEvent(Cmd.GetStream(), A.LastWrite, 0);
+                    ++R.CrossStreamWaits;
+                }
+                if (U.Access == ERGResourceAccess::Write && A.LastRead[1 - Lane]) {
+                    (void)hipStreamWaitEvent(Cmd.GetStream(), A.LastRead[1 - Lane], 0);
+                    ++R.CrossStreamWaits;
+                }
+            }
         }
 
         FTimedPass* Timed = nullptr;
@@ -421,6 +482,34 @@ void FRenderGraph::Execute(FHIPCommandContext& Cmd)
 
         if (Timed) (void)hipEventRecord(Timed->End, Cmd.GetStream());
 
+        // publish this pass's accesses for the other stream — only if a later live pass on the other stream touches one of
+        // its resources (an event record + wait costs a barrier packet on each queue)
+        bool bNeededLater = false;
+        if (bAnyAsync) {
+            for (size_t Q = P + 1; Q < NumPass && !bNeededLater; ++Q) {
+                if (!PassLive[Q] || (Passes[Q].bAsync ? 1 : 0) == Lane) continue;
+                for (const FUsage& A : Passes[Q].Usages)
+                    for (const FUsage& B : Pass.Usages)
+                        if (A.Resource == B.Resource && (A.Access == ERGResourceAccess::Write || B.Access == ERGResourceAccess::Write)) bNeededLater = true;
+            }
+        }
+        if (bNeededLater) {
+            hipEvent_t Done = Sync->Next();
+            if (Done && hipEventRecord(Done, Cmd.GetStream()) == hipSuccess) {
+                for (const FUsage& U : Pass.Usages) {
+                    FAccess& A = Access[U.Resource];
+                    if (U.Access == ERGResourceAccess::Write) {
+                        A.LastWrite = Done;
+                        A.LastWriteLane = Lane;
+                        A.LastRead[0] = A.LastRead[1] = nullptr;
+                    } else {
+                        A.LastRead[Lane] = Done;
+                    }
+                }
+            }
+        }
+        Cmd.SetAsyncLane(false);
+
         for (const FUsage& U : Pass.Usages) {
             FTexture& T = Textures[U.Resource];
             if (!T.bExternal && T.LastUsePass == static_cast<int32>(P)) ReleaseTransient(T);
@@ -428,6 +517,8 @@ void FRenderGraph::Execute(FHIPCommandContext& Cmd)
         Report.push_back(std::move(R));
     }
     if (Timings && Timings->Used > 0) Timings->bPending = true;
+    // join: later main-stream work (next frame's producers, the caller's consumers) sees the async results
+    if (bAnyAsync && Cmd.GetJoinAsyncAtEnd()) Cmd.JoinAsyncCompute();
 
     if (bEnableDebugRecording) {
         Log("RenderGraph Timing (ms):");

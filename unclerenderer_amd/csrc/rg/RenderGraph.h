@@ -86,8 +86,24 @@ public:
     FHIPCommandContext(ur_ctx* InCtx, hipStream_t InStream, uint32 InFrameCount = 3, int InRank = 0, int InWorldSize = 1)
         : Ctx(InCtx), Stream(InStream), FrameCount(InFrameCount ? InFrameCount : 1), Rank(InRank), WorldSize(InWorldSize) {}
 
-    ur_ctx* GetContext() const { return Ctx; }
-    hipStream_t GetStream() const { return Stream; }
+    // The context / stream a pass must launch on. While the graph executes a pass flagged AsyncCompute these return
+    // the async-compute pair (a second HIP stream), otherwise the main pair.
+    ur_ctx* GetContext() const { return bAsyncLane ? AsyncCtx : Ctx; }
+    hipStream_t GetStream() const { return bAsyncLane ? AsyncStream : Stream; }
+    hipStream_t GetMainStream() const { return Stream; }
+    hipStream_t GetAsyncStream() const { return AsyncStream; }
+    // MI355X extension: give the context a second stream (+ a ur_ctx bound to it) for passes flagged AsyncCompute.
+    void SetAsyncCompute(ur_ctx* InCtx, hipStream_t InStream) { AsyncCtx = InCtx; AsyncStream = InStream; }
+    bool HasAsyncCompute() const { return AsyncCtx != nullptr && AsyncStream != nullptr; }
+    void SetAsyncLane(bool bAsync) { bAsyncLane = bAsync && HasAsyncCompute(); }
+    // Join policy. true (default): Execute() ends with "main stream waits for the async stream", so anything enqueued on
+    // the main stream afterwards sees the async passes' results. false: the caller fences explicitly with
+    // JoinAsyncCompute() before main-stream work that overwrites what the async passes read or consumes what they wrote
+    // (like a D3D12 async-compute fence); successive frames' async passes are still ordered among themselves.
+    void SetJoinAsyncAtEnd(bool bJoin) { bJoinAsyncAtEnd = bJoin; }
+    bool GetJoinAsyncAtEnd() const { return bJoinAsyncAtEnd; }
+    void JoinAsyncCompute(); // main stream waits for everything submitted to the async stream so far
+    bool IsAsyncLane() const { return bAsyncLane; }
     uint32 GetCurrentFrameIndex() const { return FrameIndex; }
     uint32 GetFrameCount() const { return FrameCount; }
     int GetRank() const { return Rank; }
@@ -102,6 +118,11 @@ public:
 private:
     ur_ctx* Ctx = nullptr;
     hipStream_t Stream = nullptr;
+    ur_ctx* AsyncCtx = nullptr;
+    hipStream_t AsyncStream = nullptr;
+    bool bAsyncLane = false;
+    bool bJoinAsyncAtEnd = true;
+    hipEvent_t JoinEvent = nullptr;
     uint32 FrameCount = 3;
     uint32 FrameIndex = 0;
     uint64 FrameNumber = 0;
@@ -140,6 +161,10 @@ public:
     FRGResourceHandle ReadTexture(const FRGResourceHandle& Handle, uint32 RequiredState = RG_STATE_PIXEL_SHADER_RESOURCE);
     FRGResourceHandle WriteTexture(const FRGResourceHandle& Handle, uint32 RequiredState = RG_STATE_RENDER_TARGET);
     void KeepAlive();
+    // MI355X extension (no reference counterpart): run this pass on the context's async-compute stream. The graph
+    // orders it against main-stream passes by the declared resource usages (RAW/WAR/WAW across streams become event
+    // waits); the async stream forks from the main stream at Execute() begin and joins it at Execute() end.
+    void AsyncCompute();
 
 private:
     FRenderGraph* Graph = nullptr;
@@ -201,6 +226,8 @@ public:
         bool bCulled = false;
         uint32 Transitions = 0;
         double CpuMs = 0.0;
+        bool bAsync = false;        // ran on the async-compute stream
+        uint32 CrossStreamWaits = 0; // event waits inserted for hazards against the other stream
     };
     const std::vector<FPassReport>& GetLastExecutionReport() const { return Report; }
     FRGResourcePtr GetResource(const FRGResourceHandle& Handle) const;
@@ -236,6 +263,7 @@ private:
         std::function<void(FHIPCommandContext&)> Run;
         std::vector<FUsage> Usages;
         bool bForceExecute = false;
+        bool bAsync = false;
     };
 
     FPass& NewPass(const std::string& Name);

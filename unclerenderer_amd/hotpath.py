@@ -178,6 +178,9 @@ class Frame:
         _lib.check(self._L.ur_frame_render(self._f, C.byref(res), cc.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(scene), C.byref(sky), flags),
                    "ur_frame_render")
 
+    def join_async(self):
+        self._L.ur_frame_join_async(self._f)
+
     @property
     def hzb_ready(self) -> bool:
         return bool(self._L.ur_frame_hzb_ready(self._f))
@@ -192,9 +195,16 @@ class Frame:
         self._L.ur_frame_report(self._f, buf, n)
         out = []
         for line in buf.value.decode().splitlines():
-            name, culled, tr = line.split("|")
+            name, culled, tr, *rest = line.split("|")
             out.append((name, culled == "1", int(tr)))
         return out
+
+    def report_async(self):
+        """[(pass name, ran on the async-compute stream, cross-stream waits)] of the last executed graph."""
+        n = self._L.ur_frame_report(self._f, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.ur_frame_report(self._f, buf, n)
+        return [(f[0], f[3] == "1", int(f[4])) for f in (l.split("|") for l in buf.value.decode().splitlines())]
 
     def timing_stats(self):
         n = self._L.ur_rg_timing_stats(None, 0)
