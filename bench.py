@@ -287,7 +287,8 @@ def cpu_baseline(fc, g, shadow, env, lut, bounds, lay, W, H):
     from oracle import oracle as o
     from unclerenderer_amd import hostmath, synth
     o.build()
-    cores = o.hardware_threads()
+    # the GPU box gives one GPU a 16-core share of the host; never oversubscribe it
+    cores = max(1, min(16, len(os.sched_getaffinity(0)), o.hardware_threads()))
     o.set_threads(cores)
     t0 = time.perf_counter()
     hzb = o.build_hzb(g.depth, lay.as_list(), lay.total)

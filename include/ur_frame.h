@@ -34,6 +34,7 @@ typedef struct ur_frame_resources {
     uint32_t* visible_indices;    /* nullable */
     uint32_t* visible_count;      /* nullable */
     uint32_t* cull_stats;         /* nullable */
+    uint32_t* tonemap_band;       /* nullable: R8G8B8A8_UNORM output of the optional Tonemap pass (UR_FRAME_TONEMAP) */
 } ur_frame_resources;
 
 #define UR_FRAME_INDIRECT_DRAW 0x1u
@@ -47,6 +48,7 @@ typedef struct ur_frame_resources {
 #define UR_FRAME_BARRIER_LOGS 0x100u
 #define UR_FRAME_ASYNC_COMPUTE 0x200u /* GPU Culling + Build HZB on a second HIP stream, overlapping Lighting/Sky */
 #define UR_FRAME_ASYNC_NO_JOIN 0x400u /* with ASYNC_COMPUTE: do not end the frame with a main<-async join; the caller calls ur_frame_join_async() */
+#define UR_FRAME_TONEMAP 0x800u /* add the Tonemap pass after Sky (Exposure 0.9, Gamma 2.2, PBR-neutral curve) */
 #define UR_FRAME_DEFAULT (UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY)
 
 ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size);

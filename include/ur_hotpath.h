@@ -196,6 +196,22 @@ int ur_deferred_lighting_sky(ur_ctx* ctx, const ur_scene_constants* scene, const
                              const float* depth, const ur_lighting_tables* tables, ur_half4* hdr_inout,
                              uint32_t w, uint32_t h, uint32_t row0, uint32_t rows);
 
+/* ---- Tonemap (next row after the path) ----------------------------------------------- */
+
+/* TonemapParams root constants (Shaders/Tonemap.hlsl:22-28; FTonemapConstants, DeferredRenderer.cpp:1481-1495). */
+typedef struct ur_tonemap_constants {
+    uint32_t EnableTonemap;
+    uint32_t EnableAutoExposure;
+    float Exposure;
+    float Gamma;
+} ur_tonemap_constants;
+
+/* Tonemap.hlsl:57-79 over a band of w x rows pixels: hdr (RGBA16F) * Exposure [* 2^exposure_ev[0] when auto exposure is
+ * on; exposure_ev = device pointer to the LogAverageLuminance texel, nullable], Khronos PBR-neutral curve, saturate,
+ * pow(1/max(Gamma,1e-3)), written as R8G8B8A8_UNORM (R in the low byte, A = 255). 12 B/pixel. */
+int ur_tonemap(ur_ctx* ctx, const ur_tonemap_constants* constants, const ur_half4* hdr, const float* exposure_ev, uint32_t* out_rgba8,
+               uint32_t w, uint32_t rows);
+
 /* ---- multi-GPU: gather the row bands of the HDR frame ------------------------------------------ */
 
 /* comm: an ncclComm_t (RCCL). hdr_full: device, w*h half4 on every rank; rank r has already written

@@ -146,6 +146,20 @@ def sky_atmosphere(sky, depth, hdr, w, h, row0=0, rows=None):
     return out
 
 
+class TonemapConstants(C.Structure):
+    _fields_ = [("EnableTonemap", C.c_uint32), ("EnableAutoExposure", C.c_uint32), ("Exposure", C.c_float), ("Gamma", C.c_float)]
+
+
+def tonemap(hdr: np.ndarray, exposure=1.0, gamma=2.2, enable_tonemap=True, exposure_ev=None) -> np.ndarray:
+    """hdr: (..., 4) uint16 RGBA16F bit patterns -> (...) uint32 R8G8B8A8_UNORM."""
+    hdr = np.ascontiguousarray(hdr, np.uint16)
+    out = np.zeros(hdr.shape[:-1], np.uint32)
+    k = TonemapConstants(int(enable_tonemap), int(exposure_ev is not None), exposure, gamma)
+    ev = np.array([exposure_ev], np.float32) if exposure_ev is not None else None
+    load().uro_tonemap(C.byref(k), _p(hdr), _p(ev) if ev is not None else None, _p(out), C.c_uint32(out.size))
+    return out
+
+
 def env_cube_texels(base: int, mips: int) -> int:
     return int(load().uro_env_cube_texels(base, mips))
 

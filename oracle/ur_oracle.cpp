@@ -829,6 +829,36 @@ void uro_stage_env_cube(const ur_half4* src, uint32_t base, uint32_t mips, ur_ha
     }
 }
 
+// Tonemap.hlsl:34-79 over a band. exposure_ev: pointer to the auto-exposure texel or null.
+void uro_tonemap(const ur_tonemap_constants* K, const ur_half4* hdr, const float* exposure_ev, uint32_t* out, uint32_t count)
+{
+    float finalExposure = K->Exposure;
+    if (K->EnableAutoExposure != 0 && exposure_ev) finalExposure *= std::exp2(exposure_ev[0]);
+    const float invGamma = 1.0f / std::fmax(K->Gamma, 1e-3f);
+    for (uint32_t i = 0; i < count; ++i) {
+        float3 color = float3{h2f(hdr[i].x), h2f(hdr[i].y), h2f(hdr[i].z)} * finalExposure;
+        if (K->EnableTonemap != 0) { // PBRNeutralToneMapping
+            const float startCompression = 0.8f - 0.04f;
+            const float desaturation = 0.15f;
+            const float x = std::fmin(color.x, std::fmin(color.y, color.z));
+            const float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+            color = color - float3{offset, offset, offset};
+            const float peak = std::fmax(color.x, std::fmax(color.y, color.z));
+            if (!(peak < startCompression)) {
+                const float d = 1.0f - startCompression;
+                const float newPeak = 1.0f - d * d / (peak + d - startCompression);
+                color = color * (newPeak / std::fmax(peak, 1e-4f));
+                const float g = 1.0f - 1.0f / (desaturation * (peak - newPeak) + 1.0f);
+                color = lerp(color, float3{newPeak, newPeak, newPeak}, g);
+            }
+        }
+        color = {saturate(color.x), saturate(color.y), saturate(color.z)};
+        color = {std::pow(color.x, invGamma), std::pow(color.y, invGamma), std::pow(color.z, invGamma)};
+        auto unorm8 = [](float v) { return (uint32_t)(saturate(v) * 255.0f + 0.5f); }; // D3D float -> UNORM: round to nearest
+        out[i] = unorm8(color.x) | (unorm8(color.y) << 8) | (unorm8(color.z) << 16) | 0xFF000000u;
+    }
+}
+
 // Point probes used by the hand-derived known-answer tests.
 void uro_evaluate_pbr(const float* albedo, float metallic, float roughness, const float* F0, const float* N, const float* V,
                       const float* L, float* out3)

@@ -92,6 +92,17 @@ def test_frame_passes_and_parity(hotpath, oracle):
         assert np.array_equal(d_hzb.cpu().numpy().view(np.uint32), ref_hzb.view(np.uint32))
         want = ref_args if k == 0 else ref_args2  # first frame after the reset has no HZB yet
         assert np.array_equal(d_args.cpu().numpy().view(np.uint32), want)
+    # ---- Tonemap pass appended after Sky (next row): Exposure 0.9, Gamma 2.2, PBR-neutral
+    ldr = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    hdr4 = to_device(g.hdr)
+    res = Frame.resources(w, h, 0, h, dA, dB, dC, dD, hdr4, dD, d_hzb, lay, tables, to_device(bounds), d_args, n, 0, d_vis, d_cnt, d_stats, tonemap_band=ldr)
+    frame.render(res, consts, fc.scene, fc.sky, lib.UR_FRAME_DEFAULT | lib.UR_FRAME_TONEMAP)
+    torch.cuda.synchronize()
+    assert [r[0] for r in frame.report()] == ["GPU Culling", "Build HZB", "Lighting", "Sky", "Tonemap"]
+    ref_ldr = oracle.tonemap(hdr4.cpu().numpy().view(np.uint16), exposure=0.9, gamma=2.2)
+    sh8 = np.array([0, 8, 16, 24], np.uint32)
+    dl = np.abs(((ldr.cpu().numpy().view(np.uint32)[..., None] >> sh8) & 255).astype(np.int32) - ((ref_ldr[..., None] >> sh8) & 255).astype(np.int32))
+    assert dl.max() <= 1
     # ---- GPU timing: event pairs per pass, harvested when the slot comes round again
     for _ in range(8):
         render(lib.UR_FRAME_DEFAULT | lib.UR_FRAME_GPU_TIMING, to_device(g.hdr))

@@ -339,3 +339,25 @@ def test_cull_one_million(hotpath, oracle):
     """BASELINE config 5 (scaled HZB): 1 M instances, bit-exact words + list against the oracle."""
     cnt, stats = _cull_case(hotpath, oracle, 1_000_000, True, seed=5, w=960, h=540, box=400.0)
     assert cnt > 1000 and stats[0] > 0 and stats[1] > 0
+
+
+def test_tonemap_parity(hotpath, oracle):
+    """Next row §8f-1: 8-bit output may differ by one LSB where exp2/log2 and powf round differently."""
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    rng = np.random.default_rng(5)
+    hdr = np.zeros((64, 257, 4), np.float16)
+    hdr[..., :3] = (rng.random((64, 257, 3)) ** 3 * 6.0).astype(np.float16)
+    hdr[..., 3] = 2.0
+    hdr[0, :8, :3] = [[0, 0, 0], [1, 1, 1], [0.05, 0.05, 0.05], [8, 0.1, 0.1], [0.76, 0.76, 0.76], [65504, 0, 0], [0.08, 0.5, 0.9], [1e-4, 1e-5, 0]]
+    bits = hdr.view(np.uint16)
+    for kw in (dict(), dict(enable_tonemap=False), dict(exposure=0.9, gamma=2.2), dict(exposure=2.0, exposure_ev=-1.5)):
+        ref = oracle.tonemap(bits, **kw)
+        out = torch.zeros((64, 257), dtype=torch.int32, device="cuda")
+        ev = torch.tensor([kw["exposure_ev"]], device="cuda") if "exposure_ev" in kw else None
+        hotpath.tonemap(to_device(bits), out, 257, 64, exposure=kw.get("exposure", 1.0), gamma=kw.get("gamma", 2.2),
+                        enable_tonemap=kw.get("enable_tonemap", True), exposure_ev=ev)
+        got = out.cpu().numpy().view(np.uint32)
+        sh = np.array([0, 8, 16, 24], np.uint32)
+        d = np.abs(((got[..., None] >> sh) & 255).astype(np.int32) - ((ref[..., None] >> sh) & 255).astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())

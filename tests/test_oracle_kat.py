@@ -338,3 +338,24 @@ def test_lighting_pixel_analytic(oracle, urlib):
     got = out.view(np.float16).astype(np.float32)[0, 0]
     np.testing.assert_allclose(got[:3], want, rtol=1.2e-3)   # one fp16 rounding
     assert got[3] == 2.0                                     # ONE/ONE blend of alpha: 1 + 1
+
+
+def test_tonemap_known_answers(oracle):
+    def px(r, g, b):
+        return np.array([[r, g, b, 1.0]], np.float16).view(np.uint16)
+    unpack = lambda v: (int(v) & 255, (int(v) >> 8) & 255, (int(v) >> 16) & 255, int(v) >> 24)
+    assert unpack(oracle.tonemap(px(0, 0, 0))[0]) == (0, 0, 0, 255)
+    # gamma only: 0.5^(1/2.2) = 0.72974 -> 186
+    assert unpack(oracle.tonemap(px(0.5, 0.5, 0.5), enable_tonemap=False)[0]) == (186, 186, 186, 255)
+    # PBR neutral on white: offset .04 -> peak .96 -> newPeak = 1 - .0576/.44 = .869091 -> ^(1/2.2) = .93822 -> 239
+    assert unpack(oracle.tonemap(px(1, 1, 1))[0]) == (239, 239, 239, 255)
+    # below the compression start the curve only subtracts the toe offset: x = .05 -> offset = .05 - 6.25*.0025 = .034375
+    v = float(np.float16(0.05))
+    off = v - 6.25 * v * v
+    want = int(((v - off) ** (1 / 2.2)) * 255 + 0.5)
+    assert unpack(oracle.tonemap(px(v, v, v))[0])[0] == want
+    # exposure and auto exposure multiply: 0.25 * 2 * 2^1 = 1.0 -> same as white
+    assert unpack(oracle.tonemap(px(0.25, 0.25, 0.25), exposure=2.0, exposure_ev=1.0)[0]) == (239, 239, 239, 255)
+    # saturated channel desaturates towards the peak, never exceeds 255
+    r, g, b, a = unpack(oracle.tonemap(px(8.0, 0.1, 0.1))[0])
+    assert r > g == b and r <= 255 and g > 0

@@ -31,6 +31,7 @@ SOURCES = [
     ("hzb.hip", EXACT),
     ("cull.hip", EXACT),
     ("lighting.hip", ["-fno-slp-vectorize"]),  # packed fp32 VALU ops are not faster on gfx950 and cost v_mov traffic
+    ("tonemap.hip", []),
     ("host_math.cpp", ["-x", "hip"] + EXACT),
     ("rg/RenderGraph.cpp", ["-x", "hip"]),
     ("frame/HotPathRenderer.cpp", ["-x", "hip"]),

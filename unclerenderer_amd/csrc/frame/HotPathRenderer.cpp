@@ -152,6 +152,28 @@ int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Re
         if (rc != UR_OK && PassError == UR_OK) PassError = rc;
     });
 
+    // ---- Tonemap (DeferredRenderer.cpp:1449-1513 with TAA, auto exposure and CAS off): Lighting -> LDR band --------------
+    struct FTonemapPassData
+    {
+        bool bEnabled = false;
+        ur_tonemap_constants K;
+    };
+    if (Options.bTonemap && Res.TonemapBand) {
+        const FRGResourceHandle TonemapHandle = Graph.ImportTexture("TonemapOutput", Res.TonemapBand, &Res.TonemapState, {Res.Width, Res.Rows, RG_FORMAT_R8G8B8A8_UNORM_SRGB});
+        Graph.AddPass<FTonemapPassData>("Tonemap", [&](FTonemapPassData& Data, FRGPassBuilder& Builder)
+        {
+            Data.bEnabled = true;
+            Data.K = Constants.Tonemap;
+            Builder.ReadTexture(LightingHandle, RG_STATE_PIXEL_SHADER_RESOURCE);
+            Builder.WriteTexture(TonemapHandle, RG_STATE_RENDER_TARGET);
+        }, [this, &Res](const FTonemapPassData& Data, FHIPCommandContext& Cmd)
+        {
+            const int rc = ur_tonemap(Cmd.GetContext(), &Data.K, Res.LightingBand, nullptr, Res.TonemapBand, Res.Width, Res.Rows);
+            if (rc != UR_OK && PassError == UR_OK) PassError = rc;
+            Res.LightingState = RG_STATE_RENDER_TARGET; // the reference transitions the lighting buffer back (:1511-1512)
+        });
+    }
+
     Graph.Execute(Cmd);
     LastReport = Graph.GetLastExecutionReport();
     return PassError;
@@ -200,6 +222,7 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     R.GBufferC = const_cast<uint32*>(r->gbuffer_c);
     R.DepthBand = const_cast<float*>(r->depth_band);
     R.LightingBand = r->lighting_band;
+    R.TonemapBand = r->tonemap_band;
     R.DepthFull = const_cast<float*>(r->depth_full);
     R.HZB = r->hzb;
     std::memcpy(R.HZBMips, r->hzb_mips, sizeof(R.HZBMips));
@@ -224,6 +247,7 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     O.bRenderShadows = (flags & UR_FRAME_SHADOWS) != 0;
     O.bSkyEnabled = (flags & UR_FRAME_SKY) != 0;
     O.bFuseLightingAndSky = (flags & UR_FRAME_FUSE_LIGHTING_SKY) != 0;
+    O.bTonemap = (flags & UR_FRAME_TONEMAP) != 0;
     O.bAsyncCompute = (flags & UR_FRAME_ASYNC_COMPUTE) != 0;
     if (O.bAsyncCompute && !f->AsyncCtx) { // second stream + a context bound to it, created on first use
         int dev = 0;

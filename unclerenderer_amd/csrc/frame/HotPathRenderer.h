@@ -25,6 +25,7 @@ struct FHotPathResources
     uint32* GBufferC = nullptr;
     float* DepthBand = nullptr;
     ur_half4* LightingBand = nullptr;
+    uint32* TonemapBand = nullptr;    // optional: R8G8B8A8_UNORM output of the Tonemap pass for this band
     // full-frame depth for the replicated HZB build, and the HZB itself
     float* DepthFull = nullptr;
     float* HZB = nullptr;
@@ -46,6 +47,7 @@ struct FHotPathResources
     uint32 ShadowState = RG_STATE_DEPTH_WRITE;
     uint32 HZBState = RG_STATE_UNORDERED_ACCESS;
     uint32 LightingState = RG_STATE_RENDER_TARGET;
+    uint32 TonemapState = RG_STATE_RENDER_TARGET;
 };
 
 struct FHotPathFrameConstants
@@ -53,6 +55,7 @@ struct FHotPathFrameConstants
     uint32 CullingConstants[UR_CULL_CONSTANT_DWORDS] = {}; // packed like DispatchGpuCulling; dw 40-44 are filled per frame here
     ur_scene_constants Scene = {};
     ur_sky_constants Sky = {};
+    ur_tonemap_constants Tonemap = {1u, 0u, 0.9f, 2.2f}; // bTonemapEnabled, auto exposure off, TonemapExposure, TonemapGamma (DeferredRenderer.h:193-196)
 };
 
 struct FHotPathOptions
@@ -63,6 +66,7 @@ struct FHotPathOptions
     bool bRenderShadows = true;
     bool bSkyEnabled = true;
     bool bFuseLightingAndSky = false; // MI355X fast path: one pass, same result as Lighting followed by Sky
+    bool bTonemap = false;            // next row: Tonemap pass after Sky (TAA / auto exposure off)
     bool bAsyncCompute = false;       // MI355X: GPU Culling + Build HZB on the async-compute stream, overlapping Lighting
     bool bGpuTiming = false;
     bool bGraphDump = false;

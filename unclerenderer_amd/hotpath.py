@@ -156,7 +156,7 @@ class Frame:
 
     @staticmethod
     def resources(w, h, row0, rows, A, B, Cc, depth_band, lighting_band, depth_full, hzb, layout: HzbLayout, tables, bounds=None,
-                  indirect_args=None, command_count=0, index_base=0, visible_idx=None, visible_count=None, cull_stats=None):
+                  indirect_args=None, command_count=0, index_base=0, visible_idx=None, visible_count=None, cull_stats=None, tonemap_band=None):
         r = _lib.FrameResources()
         r.width, r.height, r.row0, r.rows = w, h, row0, rows
         dp = lambda t: t.data_ptr() if t is not None else None
@@ -170,7 +170,8 @@ class Frame:
         r.model_bounds, r.indirect_args = dp(bounds), dp(indirect_args)
         r.indirect_command_count, r.instance_index_base = command_count, index_base
         r.visible_indices, r.visible_count, r.cull_stats = dp(visible_idx), dp(visible_count), dp(cull_stats)
-        r._keep = (A, B, Cc, depth_band, lighting_band, depth_full, hzb, tables, bounds, indirect_args, visible_idx, visible_count, cull_stats)
+        r.tonemap_band = dp(tonemap_band)
+        r._keep = (A, B, Cc, depth_band, lighting_band, depth_full, hzb, tables, bounds, indirect_args, visible_idx, visible_count, cull_stats, tonemap_band)
         return r
 
     def render(self, res, culling_constants: np.ndarray, scene, sky, flags: int = _lib.UR_FRAME_DEFAULT):
@@ -211,6 +212,15 @@ class Frame:
         buf = C.create_string_buffer(n)
         self._L.ur_rg_timing_stats(buf, n)
         return [tuple(l.split("|")) for l in buf.value.decode().splitlines()]
+
+
+def _tonemap(self, hdr, out_rgba8, w, rows, exposure=1.0, gamma=2.2, enable_tonemap=True, exposure_ev=None):
+    """Tonemap pass (Tonemap.hlsl) over a band: RGBA16F -> R8G8B8A8_UNORM."""
+    k = _lib.TonemapConstants(int(enable_tonemap), int(exposure_ev is not None), exposure, gamma)
+    _lib.check(self._L.ur_tonemap(self._ctx, C.byref(k), _ptr(hdr), _ptr(exposure_ev), _ptr(out_rgba8), w, rows), "ur_tonemap")
+
+
+HotPath.tonemap = _tonemap
 
 
 def to_device(a: np.ndarray, device=0) -> torch.Tensor:

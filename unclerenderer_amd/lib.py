@@ -63,6 +63,11 @@ class LightingTables(C.Structure):
     ]
 
 
+class TonemapConstants(C.Structure):
+    """TonemapParams (Shaders/Tonemap.hlsl:22-28)."""
+    _fields_ = [("EnableTonemap", C.c_uint32), ("EnableAutoExposure", C.c_uint32), ("Exposure", C.c_float), ("Gamma", C.c_float)]
+
+
 class FrameResources(C.Structure):
     """ur_frame_resources (include/ur_frame.h)."""
     _fields_ = [
@@ -73,12 +78,13 @@ class FrameResources(C.Structure):
         ("tables", LightingTables),
         ("model_bounds", C.c_void_p), ("indirect_args", C.c_void_p), ("indirect_command_count", C.c_uint32),
         ("instance_index_base", C.c_uint32), ("visible_indices", C.c_void_p), ("visible_count", C.c_void_p), ("cull_stats", C.c_void_p),
+        ("tonemap_band", C.c_void_p),
     ]
 
 
 UR_FRAME_INDIRECT_DRAW, UR_FRAME_HZB, UR_FRAME_DEPTH_PREPASS, UR_FRAME_SHADOWS, UR_FRAME_SKY = 0x1, 0x2, 0x4, 0x8, 0x10
 UR_FRAME_FUSE_LIGHTING_SKY, UR_FRAME_GPU_TIMING, UR_FRAME_GRAPH_DUMP, UR_FRAME_BARRIER_LOGS = 0x20, 0x40, 0x80, 0x100
-UR_FRAME_ASYNC_COMPUTE, UR_FRAME_ASYNC_NO_JOIN = 0x200, 0x400
+UR_FRAME_ASYNC_COMPUTE, UR_FRAME_ASYNC_NO_JOIN, UR_FRAME_TONEMAP = 0x200, 0x400, 0x800
 UR_FRAME_DEFAULT = UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY
 
 assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
@@ -103,6 +109,7 @@ SIGNATURES = {
     "ur_sky_atmosphere": (C.c_int, [_VP, C.POINTER(SkyConstants), _VP, _VP, _U32, _U32, _U32, _U32]),
     "ur_deferred_lighting_sky": (C.c_int, [_VP, C.POINTER(SceneConstants), C.POINTER(SkyConstants), _VP, _VP, _VP, _VP,
                                            C.POINTER(LightingTables), _VP, _U32, _U32, _U32, _U32]),
+    "ur_tonemap": (C.c_int, [_VP, C.POINTER(TonemapConstants), _VP, _VP, _VP, _U32, _U32]),
     "ur_allgather_rows": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
     # ur_frame.h
     "ur_frame_create": (_VP, [_VP, _VP, _U32, C.c_int, C.c_int]),
