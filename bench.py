@@ -93,8 +93,19 @@ def main():
         depth_full = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, W, H, seed).depth
     else:
         depth_full = synth.gbuffer_iid(W, H, seed).depth
-    env = synth.env_cube_procedural(256, 9, sun_dir=fc.light_direction)
-    lut = synth.brdf_lut_procedural(128, 32)
+    # IBL tables: the reference's shipped assets (BC6H_SF16 cube decoded once on the host, RG16 LUT), kept as data
+    # fixtures under tests/golden/assets; procedural stand-ins of the same shape if they are absent
+    asset_dir = ROOT / "tests" / "golden" / "assets"
+    if (asset_dir / "output_pmrem.dds").exists() and (asset_dir / "PreintegratedGF.dds").exists():
+        from unclerenderer_amd import assets
+        env, env_base, env_mips, _ = assets.load_env_cube_dds(asset_dir / "output_pmrem.dds")
+        lut = assets.load_brdf_lut_dds(asset_dir / "PreintegratedGF.dds")
+        ibl_desc = "shipped output_pmrem.dds (BC6H_SF16 256^2 x 9 mips, decoded at setup) + PreintegratedGF.dds (RG16 128x32)"
+    else:
+        env, env_base, env_mips = synth.env_cube_procedural(256, 9, sun_dir=fc.light_direction), 256, 9
+        lut = synth.brdf_lut_procedural(128, 32)
+        ibl_desc = "procedural 256^2x9 cube + analytic LUT"
+    assert (env_base, env_mips) == (256, 9)
     gen_s = time.time() - t_gen
 
     tables = hp.make_tables(to_device(shadow, dev), hp.stage_env_cube(env, 256, 9), 256, 9, to_device(lut, dev))
@@ -205,7 +216,7 @@ def main():
             "workload": f"Sponza {W}x{H} full pipeline: cull(25) + BuildHZB({lay.count} mips) + DeferredLighting+Sky fused"
                         + (f", {N} row bands + RCCL all-gather of HDR" if N > 1 else ""),
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
-            "ibl_tables": "procedural 256^2x9 cube + analytic LUT (shipped DDS not decoded yet)",
+            "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
             "async_compute": not args.no_async, "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
         },

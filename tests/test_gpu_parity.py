@@ -361,3 +361,28 @@ def test_tonemap_parity(hotpath, oracle):
         sh = np.array([0, 8, 16, 24], np.uint32)
         d = np.abs(((got[..., None] >> sh) & 255).astype(np.int32) - ((ref[..., None] >> sh) & 255).astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())
+
+
+def test_lighting_with_shipped_ibl_assets(hotpath, oracle):
+    """Lighting parity with the reference's own IBL tables: output_pmrem.dds (BC6H_SF16, decoded by csrc/dds.cpp) and
+    PreintegratedGF.dds, 9 mips, EnvMapMipCount = 9."""
+    from pathlib import Path
+    from unclerenderer_amd import assets, hostmath, synth
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    adir = Path(__file__).parent / "golden" / "assets"
+    env, base, mips, bad = assets.load_env_cube_dds(adir / "output_pmrem.dds")
+    lut = assets.load_brdf_lut_dds(adir / "PreintegratedGF.dds")
+    assert (base, mips, bad) == (256, 9, 0)
+    w, h = 320, 180
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=256, env_mip_count=9)
+    shadow = synth.shadow_map_noise(256, 77)
+    tables = hotpath.make_tables(to_device(shadow), hotpath.stage_env_cube(env, base, mips), base, mips, to_device(lut))
+    for g in (synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 77), synth.gbuffer_iid(w, h, 77)):
+        lit, frag = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, base, mips, lut, g.hdr, w, h, want_fragile=True)
+        ref = oracle.sky_atmosphere(fc.sky, g.depth, lit, w, h)
+        hdr = to_device(g.hdr)
+        hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, hdr, w, h)
+        torch.cuda.synchronize()
+        nbad, worst, _ = hdr_mismatch(hdr.cpu().numpy().view(np.uint16), ref, exclude=frag)
+        assert nbad == 0, (nbad, worst)

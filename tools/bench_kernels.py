@@ -47,8 +47,14 @@ def main():
     hp = HotPath(0)
     W, H = a.width, a.height
     fc = hostmath.build_frame_constants("sponza", W, H)
-    env = synth.env_cube_procedural(256, 9, sun_dir=fc.light_direction)
-    lut = synth.brdf_lut_procedural(128, 32)
+    asset_dir = Path(__file__).resolve().parent.parent / "tests" / "golden" / "assets"
+    if (asset_dir / "output_pmrem.dds").exists():
+        from unclerenderer_amd import assets
+        env = assets.load_env_cube_dds(asset_dir / "output_pmrem.dds")[0]
+        lut = assets.load_brdf_lut_dds(asset_dir / "PreintegratedGF.dds")
+    else:
+        env = synth.env_cube_procedural(256, 9, sun_dir=fc.light_direction)
+        lut = synth.brdf_lut_procedural(128, 32)
     d_env = hp.stage_env_cube(env, 256, 9)
     modes = ["scene", "iid"] if a.gbuffer == "both" else [a.gbuffer]
     for mode in modes if not a.no_light else []:

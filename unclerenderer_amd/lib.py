@@ -63,6 +63,11 @@ class LightingTables(C.Structure):
     ]
 
 
+class DdsInfo(C.Structure):
+    """ur_dds_info (include/ur_assets.h)."""
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "mip_count", "slices", "is_cube", "dxgi_format", "header_size", "block_dim", "bytes_per_block")]
+
+
 class TonemapConstants(C.Structure):
     """TonemapParams (Shaders/Tonemap.hlsl:22-28)."""
     _fields_ = [("EnableTonemap", C.c_uint32), ("EnableAutoExposure", C.c_uint32), ("Exposure", C.c_float), ("Gamma", C.c_float)]
@@ -111,6 +116,12 @@ SIGNATURES = {
                                            C.POINTER(LightingTables), _VP, _U32, _U32, _U32, _U32]),
     "ur_tonemap": (C.c_int, [_VP, C.POINTER(TonemapConstants), _VP, _VP, _VP, _U32, _U32]),
     "ur_allgather_rows": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
+    # ur_assets.h
+    "ur_dds_parse": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo)]),
+    "ur_dds_texel_count": (C.c_size_t, [C.POINTER(DdsInfo)]),
+    "ur_dds_decode_rgba16f": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo), _VP, C.POINTER(_U32)]),
+    "ur_dds_copy_rg16": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo), _VP]),
+    "ur_bc6h_decode_block": (C.c_int, [_VP, C.c_int, _VP]),
     # ur_frame.h
     "ur_frame_create": (_VP, [_VP, _VP, _U32, C.c_int, C.c_int]),
     "ur_frame_destroy": (None, [_VP]),
