@@ -386,3 +386,32 @@ def test_lighting_with_shipped_ibl_assets(hotpath, oracle):
         torch.cuda.synchronize()
         nbad, worst, _ = hdr_mismatch(hdr.cpu().numpy().view(np.uint16), ref, exclude=frag)
         assert nbad == 0, (nbad, worst)
+
+
+@pytest.mark.parametrize("scene_name,file,count", [("pica_pica", "pica_pica", 170), ("duck", "Duck", 1), ("sponza", "sponza", 25)])
+def test_cull_on_shipped_scene_bounds(hotpath, oracle, scene_name, file, count):
+    """BASELINE configs 1/3/4: the cull over the scenes' real draw-command AABBs (csrc/scene.cpp extraction), HZB from a
+    synthetic depth through the scene's own camera."""
+    from pathlib import Path
+    from unclerenderer_amd import hostmath, scene, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    torch = _torch()
+    sb = scene.load_scene_bounds(Path(__file__).parent / "golden" / "assets" / "Scenes" / f"{file}.json")
+    assert sb.count == count
+    w, h = 512, 288
+    fc = hostmath.build_frame_constants(scene_name, w, h)
+    depth = (synth.hash_unit(9, *synth._grid(w, 0, h), 0) * np.float32(0.004)).astype(np.float32)  # far-ish random depth: some boxes hide, some do not
+    lay = HzbLayout(w, h)
+    hzb = np.nan_to_num(oracle.build_hzb(depth, lay.as_list(), lay.total))
+    for hzb_on in (False, True):
+        consts = hostmath.pack_culling_constants(fc.view, fc.proj, count, hzb_on, lay.count, lay.width, lay.height, True)
+        args0 = synth.indirect_args_initial(count)
+        ref_args, ref_stats, ref_vis, ref_cnt = oracle.cull_indirect_args(consts, sb.bounds, hzb, lay.as_list(), args0)
+        d_args, d_stats = to_device(args0), torch.zeros(2, dtype=torch.int32, device="cuda")
+        d_vis, d_cnt = torch.zeros(count, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+        hotpath.cull_indirect_args(consts, to_device(sb.bounds), to_device(hzb), lay, d_args, d_stats, d_vis, d_cnt)
+        assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args)
+        assert int(d_cnt.cpu()[0]) == ref_cnt and np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt], ref_vis)
+        assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats)
+    if scene_name == "pica_pica":
+        assert 0 < ref_cnt <= count

@@ -103,18 +103,25 @@ class ScenePreset:
     # node's +90deg X rotation, LH z flip (GltfLoader.cpp:823), scale 0.01, translate (5,0,0) (sponza.json)
     model_aabb: tuple = ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
     instance_count: int = 1
+    # scene centre / radius as CreateSceneModelsFromJson derives them (union of per-command spheres); values produced by
+    # ur_scene_extract (csrc/scene.cpp) on the shipped scene files and pinned by tests/test_scene.py
+    scene_center: tuple | None = None
+    scene_radius: float | None = None
 
 
 SCENES = {
     "sponza": ScenePreset("sponza", (14.327, 0.762, 0.571), camera_rotation_deg=(-12.6, 261.8, 0.0), fov_y_deg=60.0,
                           light_rotation_deg=(-75.0, 0.0, 0.0), light_intensity=1.0, light_color=(1.0, 1.0, 1.0),
-                          model_aabb=((-14.209459, -1.264425, -11.054260), (22.999081, 14.294332, 11.828071)), instance_count=25),
+                          model_aabb=((-14.209459, -1.264425, -11.054260), (22.999081, 14.294332, 11.828071)), instance_count=25,
+                          scene_center=(4.3948116, 6.5149517, 0.38690376), scene_radius=40.15736),
     "duck": ScenePreset("duck", (0.0, 1.5, 4.0), camera_look_at=(0.0, 1.0, 0.0), fov_y_deg=60.0,
                         light_direction=(-0.5, -1.0, -0.3), light_intensity=3.0, light_color=(1.0, 0.95, 0.9),
-                        model_aabb=((-0.692985, 0.099370, -0.613282), (0.961799, 1.640030, 0.539252)), instance_count=1),
+                        model_aabb=((-0.692985, 0.09929369, -0.539252), (0.96179897, 1.6396999, 0.61328197)), instance_count=1,
+                        scene_center=(0.13440704, 0.8694968, 0.03701496), scene_radius=2.1976402),
     "pica_pica": ScenePreset("pica_pica", (-13.482, 20.457, -42.455), camera_rotation_deg=(19.199, 16.599, 0.0), fov_y_deg=60.0,
                              light_rotation_deg=(-45.0, -135.0, 0.0), light_intensity=1.0, light_color=(1.0, 0.95, 0.9),
-                             model_aabb=((-30.0, -2.0, -30.0), (30.0, 25.0, 30.0)), instance_count=170),
+                             model_aabb=((-36.92157, -1.1695042, -18.168373), (27.365425, 18.529217, 32.19241)), instance_count=170,
+                             scene_center=(-3.2157097, 3.8195744, 1.1750641), scene_radius=62.74809),
 }
 
 
@@ -155,11 +162,13 @@ def build_frame_constants(preset: ScenePreset | str, width: int, height: int, *,
     else:
         jd = direction_from_euler_degrees(preset.light_rotation_deg[0], preset.light_rotation_deg[1])
     light_dir = light_direction_roundtrip(jd)
-    # scene bounds: one model sphere (centre of the AABB, half its diagonal, >= 1) -> box -> centre / radius
-    mn, mx = _f(*preset.model_aabb[0]), _f(*preset.model_aabb[1])
-    center = ((mn + mx) * np.float32(0.5)).astype(np.float32)
-    model_radius = max(float(np.sqrt(((mx - mn) ** 2).sum())) * 0.5, 1.0)
-    scene_radius = max(float(np.sqrt(3.0 * (2.0 * model_radius) ** 2)) * 0.5, 1.0)
+    if preset.scene_center is not None and preset.scene_radius is not None:
+        center, scene_radius = _f(*preset.scene_center), float(preset.scene_radius)
+    else:  # one model sphere (centre of the AABB, half its diagonal, >= 1) -> box -> centre / radius
+        mn, mx = _f(*preset.model_aabb[0]), _f(*preset.model_aabb[1])
+        center = ((mn + mx) * np.float32(0.5)).astype(np.float32)
+        model_radius = max(float(np.sqrt(((mx - mn) ** 2).sum())) * 0.5, 1.0)
+        scene_radius = max(float(np.sqrt(3.0 * (2.0 * model_radius) ** 2)) * 0.5, 1.0)
     sky_radius = max(scene_radius * 5.0, 100.0)  # DeferredRenderer.cpp:349
     lvp = light_view_projection(center, scene_radius, light_dir)
     scene = _lib.SceneConstants()

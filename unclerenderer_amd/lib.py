@@ -68,6 +68,17 @@ class DdsInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "mip_count", "slices", "is_cube", "dxgi_format", "header_size", "block_dim", "bytes_per_block")]
 
 
+class SceneModel(C.Structure):
+    """ur_scene_model (include/ur_scene.h)."""
+    _fields_ = [("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("center", C.c_float * 3), ("radius", C.c_float),
+                ("pipeline_key", C.c_uint32), ("material_index", C.c_uint32), ("model_index", C.c_uint32), ("node_order", C.c_uint32),
+                ("mesh_index", C.c_uint32), ("primitive_index", C.c_uint32)]
+
+
+class SceneSummary(C.Structure):
+    _fields_ = [("model_count", C.c_uint32), ("scene_center", C.c_float * 3), ("scene_radius", C.c_float)]
+
+
 class TonemapConstants(C.Structure):
     """TonemapParams (Shaders/Tonemap.hlsl:22-28)."""
     _fields_ = [("EnableTonemap", C.c_uint32), ("EnableAutoExposure", C.c_uint32), ("Exposure", C.c_float), ("Gamma", C.c_float)]
@@ -122,6 +133,10 @@ SIGNATURES = {
     "ur_dds_decode_rgba16f": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo), _VP, C.POINTER(_U32)]),
     "ur_dds_copy_rg16": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo), _VP]),
     "ur_bc6h_decode_block": (C.c_int, [_VP, C.c_int, _VP]),
+    # ur_scene.h
+    "ur_scene_model_count": (C.c_int, [C.c_char_p]),
+    "ur_scene_model_path": (C.c_int, [C.c_char_p, _U32, C.c_char_p, _U32]),
+    "ur_scene_extract": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), _U32, C.POINTER(SceneModel), _U32, C.POINTER(SceneSummary)]),
     # ur_frame.h
     "ur_frame_create": (_VP, [_VP, _VP, _U32, C.c_int, C.c_int]),
     "ur_frame_destroy": (None, [_VP]),
