@@ -212,6 +212,14 @@ typedef struct ur_tonemap_constants {
 int ur_tonemap(ur_ctx* ctx, const ur_tonemap_constants* constants, const ur_half4* hdr, const float* exposure_ev, uint32_t* out_rgba8,
                uint32_t w, uint32_t rows);
 
+/* ---- TemporalAA resolve (next row; Shaders/TemporalAA.hlsl:12-50, DeferredRenderer.cpp:1308-1361) ---- */
+
+/* current_frame: device, the FULL w x h RGBA16F frame (the 3x3 neighbourhood of a band's edge rows lies outside the
+ * band; with multi-GPU sharding this is the all-gathered frame). history_band / output_band: band-local rows
+ * [row0,row0+rows). use_history == 0 copies current (first frame). Bit-exact against the oracle. 24 B/pixel. */
+int ur_temporal_aa(ur_ctx* ctx, const ur_half4* current_frame, const ur_half4* history_band, ur_half4* output_band, float history_weight,
+                   uint32_t use_history, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows);
+
 /* ---- multi-GPU: gather the row bands of the HDR frame ------------------------------------------ */
 
 /* comm: an ncclComm_t (RCCL). hdr_full: device, w*h half4 on every rank; rank r has already written

@@ -160,6 +160,18 @@ def tonemap(hdr: np.ndarray, exposure=1.0, gamma=2.2, enable_tonemap=True, expos
     return out
 
 
+def temporal_aa(current: np.ndarray, history: np.ndarray, history_weight: float, use_history: bool, row0: int = 0, rows=None) -> np.ndarray:
+    """current: (H, W, 4) uint16 full frame; history: (rows, W, 4) band. Returns the resolved band."""
+    current = np.ascontiguousarray(current, np.uint16)
+    H, W = current.shape[:2]
+    rows = H - row0 if rows is None else rows
+    history = np.ascontiguousarray(history, np.uint16)
+    out = np.zeros((rows, W, 4), np.uint16)
+    load().uro_temporal_aa(_p(current), _p(history), _p(out), C.c_float(history_weight), C.c_uint32(int(use_history)), C.c_uint32(W), C.c_uint32(H),
+                           C.c_uint32(row0), C.c_uint32(rows))
+    return out
+
+
 def env_cube_texels(base: int, mips: int) -> int:
     return int(load().uro_env_cube_texels(base, mips))
 

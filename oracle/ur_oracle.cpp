@@ -859,6 +859,36 @@ void uro_tonemap(const ur_tonemap_constants* K, const ur_half4* hdr, const float
     }
 }
 
+// TemporalAA.hlsl:12-50 for band rows [row0,row0+rows); current = full frame, history/output band-local.
+void uro_temporal_aa(const ur_half4* current, const ur_half4* history, ur_half4* output, float HistoryWeight, uint32_t UseHistory, uint32_t W,
+                     uint32_t H, uint32_t row0, uint32_t rows)
+{
+    const float w = saturate(HistoryWeight);
+    for (uint32_t r = 0; r < rows; ++r)
+        for (uint32_t x = 0; x < W; ++x) {
+            const int px = (int)x, py = (int)(row0 + r);
+            const ur_half4 Current = current[(size_t)py * W + px];
+            const size_t bi = (size_t)r * W + x;
+            if (UseHistory == 0) { output[bi] = Current; continue; }
+            float3 MinColor = {h2f(Current.x), h2f(Current.y), h2f(Current.z)}, MaxColor = MinColor;
+            for (int oy = -1; oy <= 1; ++oy)
+                for (int ox = -1; ox <= 1; ++ox) {
+                    const int sx = std::min(std::max(px + ox, 0), (int)W - 1), sy = std::min(std::max(py + oy, 0), (int)H - 1);
+                    const ur_half4 s = current[(size_t)sy * W + sx];
+                    const float3 c = {h2f(s.x), h2f(s.y), h2f(s.z)};
+                    MinColor = {std::fmin(MinColor.x, c.x), std::fmin(MinColor.y, c.y), std::fmin(MinColor.z, c.z)};
+                    MaxColor = {std::fmax(MaxColor.x, c.x), std::fmax(MaxColor.y, c.y), std::fmax(MaxColor.z, c.z)};
+                }
+            const ur_half4 hh = history[bi];
+            float3 Hist = {h2f(hh.x), h2f(hh.y), h2f(hh.z)};
+            Hist = {std::fmin(std::fmax(Hist.x, MinColor.x), MaxColor.x), std::fmin(std::fmax(Hist.y, MinColor.y), MaxColor.y),
+                    std::fmin(std::fmax(Hist.z, MinColor.z), MaxColor.z)};
+            const float3 Cur = {h2f(Current.x), h2f(Current.y), h2f(Current.z)};
+            const float3 Blended = lerp(Cur, Hist, w);
+            output[bi] = {f2h(Blended.x), f2h(Blended.y), f2h(Blended.z), Current.w};
+        }
+}
+
 // Point probes used by the hand-derived known-answer tests.
 void uro_evaluate_pbr(const float* albedo, float metallic, float roughness, const float* F0, const float* N, const float* V,
                       const float* L, float* out3)

@@ -415,3 +415,27 @@ def test_cull_on_shipped_scene_bounds(hotpath, oracle, scene_name, file, count):
         assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats)
     if scene_name == "pica_pica":
         assert 0 < ref_cnt <= count
+
+
+@pytest.mark.parametrize("w,h", [(64, 8), (67, 13), (320, 180), (1, 1), (130, 3)])
+def test_temporal_aa_bit_exact(hotpath, oracle, w, h):
+    """Next row §8f-4: LDS-tiled 3x3 clamp + blend, whole frame and 3 uneven row bands, bit for bit."""
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    rng = np.random.default_rng(w * 31 + h)
+    cur = (rng.random((h, w, 4)) ** 2 * 8).astype(np.float16)
+    hist = (rng.random((h, w, 4)) ** 2 * 8).astype(np.float16)
+    cur[..., 3] = 2.0
+    cb, hb = cur.view(np.uint16), hist.view(np.uint16)
+    d_cur, d_hist = to_device(cb), to_device(hb)
+    for use, wt in ((True, 0.9), (True, 0.35), (False, 0.9)):
+        ref = oracle.temporal_aa(cb, hb, wt, use)
+        out = torch.zeros((h, w, 4), dtype=torch.int16, device="cuda")
+        hotpath.temporal_aa(d_cur, d_hist, out, wt, use, w, h)
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), ref)
+        parts = torch.zeros((h, w, 4), dtype=torch.int16, device="cuda")
+        cuts = sorted({0, h // 3, (2 * h) // 3 + (1 if h > 2 else 0), h})
+        for a, b in zip(cuts, cuts[1:]):
+            if b > a:
+                hotpath.temporal_aa(d_cur, d_hist[a:b], parts[a:b], wt, use, w, h, a, b - a)
+        assert torch.equal(parts, out)

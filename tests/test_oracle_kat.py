@@ -359,3 +359,24 @@ def test_tonemap_known_answers(oracle):
     # saturated channel desaturates towards the peak, never exceeds 255
     r, g, b, a = unpack(oracle.tonemap(px(8.0, 0.1, 0.1))[0])
     assert r > g == b and r <= 255 and g > 0
+
+
+def test_temporal_aa_known_answers(oracle):
+    h16 = lambda a: np.asarray(a, np.float16).view(np.uint16)
+    cur = np.zeros((3, 3, 4), np.float16)
+    cur[..., :3] = 0.5
+    cur[1, 1, :3] = [1.0, 0.25, 0.5]
+    cur[..., 3] = 2.0
+    hist = np.zeros((3, 3, 4), np.float16)
+    hist[..., :3] = [4.0, 0.0, 0.5]   # red above the box, green below it, blue inside
+    out = oracle.temporal_aa(h16(cur), h16(hist), 0.9, True).view(np.float16).astype(np.float32)
+    # centre pixel: box r [0.5,1], g [0.25,0.5], b [0.5,0.5]; history clamps to (1, 0.25, 0.5) = current -> unchanged
+    assert out[1, 1].tolist() == [1.0, 0.25, 0.5, 2.0]
+    # corner pixel (0,0): neighbourhood (clamped at the frame edge) holds 0.5 everywhere plus the centre pixel
+    # -> box r [0.5,1], g [0.25,0.5], b 0.5; history -> (1, 0.25, 0.5); blend 0.5 + 0.9*(h-0.5)
+    want = np.array([0.5 + 0.9 * 0.5, 0.5 + 0.9 * (0.25 - 0.5), 0.5], np.float32).astype(np.float16).astype(np.float32)
+    assert np.array_equal(out[0, 0, :3], want) and out[0, 0, 3] == 2.0
+    # no history: pass-through; weight saturates
+    assert np.array_equal(oracle.temporal_aa(h16(cur), h16(hist), 0.9, False), h16(cur))
+    assert np.array_equal(oracle.temporal_aa(h16(cur), h16(hist), 7.0, True), oracle.temporal_aa(h16(cur), h16(hist), 1.0, True))
+    assert np.array_equal(oracle.temporal_aa(h16(cur), h16(hist), -1.0, True)[..., :3], h16(cur)[..., :3])

@@ -32,6 +32,7 @@ SOURCES = [
     ("cull.hip", EXACT),
     ("lighting.hip", ["-fno-slp-vectorize"]),  # packed fp32 VALU ops are not faster on gfx950 and cost v_mov traffic
     ("tonemap.hip", []),
+    ("taa.hip", EXACT),
     ("scene.cpp", ["-x", "hip"] + EXACT),
     ("dds.cpp", ["-x", "hip"] + EXACT),
     ("host_math.cpp", ["-x", "hip"] + EXACT),

@@ -223,6 +223,16 @@ def _tonemap(self, hdr, out_rgba8, w, rows, exposure=1.0, gamma=2.2, enable_tone
 HotPath.tonemap = _tonemap
 
 
+def _temporal_aa(self, current_frame, history_band, output_band, history_weight, use_history, w, h, row0=0, rows=None):
+    """TemporalAA resolve (TemporalAA.hlsl): current = full frame, history/output = band rows [row0,row0+rows)."""
+    rows = h - row0 if rows is None else rows
+    _lib.check(self._L.ur_temporal_aa(self._ctx, _ptr(current_frame), _ptr(history_band), _ptr(output_band), history_weight, int(use_history), w, h, row0, rows),
+               "ur_temporal_aa")
+
+
+HotPath.temporal_aa = _temporal_aa
+
+
 def to_device(a: np.ndarray, device=0) -> torch.Tensor:
     """numpy -> device tensor, reinterpreting unsigned dtypes torch cannot hold (bit patterns are preserved)."""
     a = np.ascontiguousarray(a)

@@ -126,6 +126,7 @@ SIGNATURES = {
     "ur_deferred_lighting_sky": (C.c_int, [_VP, C.POINTER(SceneConstants), C.POINTER(SkyConstants), _VP, _VP, _VP, _VP,
                                            C.POINTER(LightingTables), _VP, _U32, _U32, _U32, _U32]),
     "ur_tonemap": (C.c_int, [_VP, C.POINTER(TonemapConstants), _VP, _VP, _VP, _U32, _U32]),
+    "ur_temporal_aa": (C.c_int, [_VP, _VP, _VP, _VP, _F, _U32, _U32, _U32, _U32, _U32]),
     "ur_allgather_rows": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
     # ur_assets.h
     "ur_dds_parse": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo)]),
