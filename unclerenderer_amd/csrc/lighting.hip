@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -259,8 +260,17 @@ __device__ __noinline__ float shadow_pcf_border(const float* __restrict__ map, i
 }
 
 // DeferredLighting.hlsl:35-94 for one pixel. (a,b) = camera ray (ndc.x/P11, -ndc.y/P22); viewPos = viewZ * (a, b, 1).
-template <bool SHADOWS>
-__device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* srgb, float ra, float rb, half4_t ga, half4_t gb, uint32_t gc)
+template <class T, class = void> struct ur_has_fence { static constexpr bool value = true; };
+template <class T> struct ur_has_fence<T, std::void_t<decltype(std::decay_t<T>::kFence)>> { static constexpr bool value = std::decay_t<T>::kFence; };
+struct NoPrefetch { static constexpr bool kFence = false; __device__ __forceinline__ void operator()() const {} };
+
+// `mipOffset`: the per-mip texel offsets (LDS copy in the persistent kernel: a per-lane indexed read of the kernarg copy is
+// a dependent global load in front of the cube gathers). `after_gathers` runs once every gather of this pixel has been
+// issued and before their results are consumed: loads issued inside it are YOUNGER than the gathers, so the waits on the
+// gathers (in-order vmcnt) do not wait for them — that is where the persistent kernel prefetches the next tile.
+template <bool SHADOWS, class AfterGathers>
+__device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* srgb, const uint32_t* mipOffset, float ra, float rb, half4_t ga, half4_t gb,
+                                          uint32_t gc, AfterGathers&& after_gathers)
 {
     // ---- decode, view vectors ------------------------------------------------------------------------------------------
     const float nx = (float)ga.x, ny = (float)ga.y, nz = (float)ga.z;
@@ -284,14 +294,18 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     const float lvl = fminf(fmaxf(roughness * p.maxMip, 0.0f), (float)(p.envMips - 1u));
     const uint32_t m0 = (uint32_t)lvl, m1 = min(m0 + 1u, p.envMips - 1u);
     const float fl = lvl - (float)m0; // m1 == m0 only when fl == 0: the second mip then carries weight 0
-    const CubeTaps pre0 = cube_taps_load(p.env, p.envMipOffset[m0], max(1u, p.envBase >> m0), cr);
-    const CubeTaps pre1 = cube_taps_load(p.env, p.envMipOffset[m1], max(1u, p.envBase >> m1), cr);
+    const CubeTaps pre0 = cube_taps_load(p.env, mipOffset[m0], max(1u, p.envBase >> m0), cr);
+    const CubeTaps pre1 = cube_taps_load(p.env, mipOffset[m1], max(1u, p.envBase >> m1), cr);
     const CubeTaps irr0 = cube_taps_load(p.env, p.irrOffset0, p.irrN0, cn);
     const LutTaps lut = lut_taps_load(p, NdotV, roughness);
+    // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF altogether
+    // (same result: direct = 0). Coherent G-buffers make this common (ceilings, walls turned from the sun).
+    const float NdotL = sat(dot(N, L));
+    const bool wave_lit = SHADOWS && __any(NdotL > 0.0f);
     float su = 0.0f, sv = 0.0f, cmp = 0.0f;
     bool lit = false;
     ShadowTaps sh;
-    if (SHADOWS) {
+    if (wave_lit) {
         // shadow clip = viewZ * ((a,b,1) * M3) + M[3]
         const float qx = fmaf(rb, p.SQ[4], fmaf(ra, p.SQ[0], p.SQ[8]));
         const float qy = fmaf(rb, p.SQ[5], fmaf(ra, p.SQ[1], p.SQ[9]));
@@ -305,12 +319,18 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
         sh = shadow_taps_load(p, su, sv);
     }
     const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
+    if constexpr (ur_has_fence<AfterGathers>::value) {
+        __builtin_amdgcn_sched_barrier(0); // keep the prefetch loads behind the gathers in issue order
+        after_gathers();
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        after_gathers();
+    }
 
     // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) --------------------------------------------
     const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
     F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
     const float hr = rsq(dot(Hv, Hv));
-    const float NdotL = sat(dot(N, L));
     const float NdotH = sat(dot(N, Hv) * hr);
     const float VdotH = dot(V, Hv) * hr; // = (1 + V.L)/|V + L| in [0,1]: saturate is the identity up to rounding
     const float alpha = roughness * roughness;
@@ -330,7 +350,7 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
 
     // ---- filter ---------------------------------------------------------------------------------------------------------------
     float shadow = 1.0f;
-    if (SHADOWS) {
+    if (wave_lit) {
         const bool fast = sh.ia >= 0 && sh.ja >= 0 && sh.ia + 2 < p.shadowWi && sh.ja + 2 < p.shadowHi;
         float s = shadow_taps_filter(sh, cmp);
         if (__builtin_expect(lit && !fast, 0)) {
@@ -352,9 +372,11 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     F3 color;
 #define UR_CHANNEL(ch, i)                                                                                     \
     {                                                                                                         \
+        const float A = kdm * albedo.ch;                     /* (1 - metallic) * albedo: diffuse weight, also irradiance's */ \
         const float F = fmaf(1.0f - F0.ch, p5, F0.ch);                                                        \
-        const float direct = fmaf((1.0f - F) * kdm, albedo.ch, sc * F) * (p.lightRGB[i] * sh_l);              \
-        color.ch = fmaf(irradiance.ch * albedo.ch, kdm, fmaf(prefiltered.ch, fmaf(F0.ch, ba, bb), direct));   \
+        const float direct = fmaf(F, sc - A, A);             /* (1-F) A + F sc */                            \
+        const float ambient = fmaf(irradiance.ch, A, prefiltered.ch * fmaf(F0.ch, ba, bb));                   \
+        color.ch = fmaf(direct, p.lightRGB[i] * sh_l, ambient);                                               \
     }
     UR_CHANNEL(x, 0)
     UR_CHANNEL(y, 1)
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
     const half4_t ga = ld<half4_t>(p.A, i * 8u), gb = ld<half4_t>(p.B, i * 8u);
     const uint32_t gc = ld<uint32_t>(p.C, i * 4u);
     const half4_t d = ld<half4_t>(p.hdr, i * 8u);
-    const F3 col = shade_pixel<SHADOWS>(p, srgb, ndcx * p.invP11, -ndcy * p.invP22, ga, gb, gc);
+    const F3 col = shade_pixel<SHADOWS>(p, srgb, p.envMipOffset, ndcx * p.invP11, -ndcy * p.invP22, ga, gb, gc, NoPrefetch{});
     half4_t o;
     o.x = (_Float16)((float)d.x + col.x);
     o.y = (_Float16)((float)d.y + col.y);
@@ -465,7 +487,9 @@ __global__ __launch_bounds__(256) void lighting_kernel_persistent(LightingParams
 {
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the simple kernel");
     __shared__ float srgb[256];
+    __shared__ uint32_t mipOffset[16];
     srgb[threadIdx.x] = p.srgb[threadIdx.x];
+    if (threadIdx.x < 16u) mipOffset[threadIdx.x] = p.envMipOffset[threadIdx.x];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t tile = blockIdx.x;
@@ -474,32 +498,34 @@ __global__ __launch_bounds__(256) void lighting_kernel_persistent(LightingParams
     for (;;) {
         const uint32_t next = tile + gridDim.x;
         const bool more = next < numTiles; // uniform
-        PixelIn nxt = cur;
-        if (more) nxt = fetch_pixel<MODE, TW>(p, next, tilesX, lane, wave);
+        // The prefetch is issued unconditionally (the last iteration re-reads its own tile): a branch around it would
+        // make the compiler's s_waitcnt bookkeeping assume "no younger loads" and wait vmcnt(0) on the gathers.
+        const uint32_t pf = more ? next : tile;
+        PixelIn nxt;
+        const float ndcx = fmaf((float)cur.px + 0.5f, p.invW2, -1.0f);
+        const float ndcy = fmaf((float)cur.py + 0.5f, p.invH2, -1.0f);
+        bool sky = false;
+        F3 out = f3(0.0f, 0.0f, 0.0f);
+        if (MODE == ur::UR_MODE_FUSED) {
+            const float vx = ndcx * p.skyInvP11, vy = -ndcy * p.skyInvP22;
+            const float len = __builtin_amdgcn_sqrtf(fmaf(vx, vx, fmaf(vy, vy, 1.0f)));
+            sky = p.skyNearOverR * len >= cur.depth;
+            if (sky) out = sky_pixel(p, vx, vy);
+        }
+        // Shade when any lane of the wave has geometry (wave-uniform branch, so the prefetch inside runs for every lane);
+        // sky / out-of-frame lanes compute on whatever they loaded and their result is dropped.
+        if (__any(cur.valid && !sky)) {
+            const F3 col = shade_pixel<SHADOWS>(p, srgb, mipOffset, ndcx * p.invP11, -ndcy * p.invP22, cur.a, cur.b, cur.c,
+                                                [&] { nxt = fetch_pixel<MODE, TW>(p, pf, tilesX, lane, wave); });
+            if (!sky) out = f3((float)cur.d.x + col.x, (float)cur.d.y + col.y, (float)cur.d.z + col.z);
+        } else {
+            nxt = fetch_pixel<MODE, TW>(p, pf, tilesX, lane, wave);
+        }
         if (cur.valid) {
-            const float ndcx = fmaf((float)cur.px + 0.5f, p.invW2, -1.0f);
-            const float ndcy = fmaf((float)cur.py + 0.5f, p.invH2, -1.0f);
-            bool sky = false;
-            if (MODE == ur::UR_MODE_FUSED) {
-                const float vx = ndcx * p.skyInvP11, vy = -ndcy * p.skyInvP22;
-                const float len = __builtin_amdgcn_sqrtf(fmaf(vx, vx, fmaf(vy, vy, 1.0f)));
-                sky = p.skyNearOverR * len >= cur.depth;
-                if (sky) {
-                    const F3 c = sky_pixel(p, vx, vy);
-                    half4_t o;
-                    o.x = (_Float16)c.x; o.y = (_Float16)c.y; o.z = (_Float16)c.z; o.w = (_Float16)1.0f;
-                    st<half4_t>(p.hdr, cur.i * 8u, o);
-                }
-            }
-            if (!sky) {
-                const F3 col = shade_pixel<SHADOWS>(p, srgb, ndcx * p.invP11, -ndcy * p.invP22, cur.a, cur.b, cur.c);
-                half4_t o;
-                o.x = (_Float16)((float)cur.d.x + col.x);
-                o.y = (_Float16)((float)cur.d.y + col.y);
-                o.z = (_Float16)((float)cur.d.z + col.z);
-                o.w = (_Float16)((float)cur.d.w + 1.0f);
-                st<half4_t>(p.hdr, cur.i * 8u, o);
-            }
+            half4_t o;
+            o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z;
+            o.w = sky ? (_Float16)1.0f : (_Float16)((float)cur.d.w + 1.0f);
+            st<half4_t>(p.hdr, cur.i * 8u, o);
         }
         if (!more) break;
         cur = nxt;
@@ -536,9 +562,12 @@ void launch_tile_shape(ur_ctx* ctx, const LightingParams& p)
         }
     }
     // register budget: waves/SIMD the kernel is compiled for (6 -> 80 VGPRs, 4 -> no cap)
-    static const int waves = env_int("UR_LIGHTING_WAVES", 4); // measured: 86 VGPRs without a cap beats an 80-VGPR build that spills
-    if (waves >= 6) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 4>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
+    static const int waves = env_int("UR_LIGHTING_WAVES", 6); // measured T ~ 65 us + 247 us / waves-per-SIMD: 6 waves (80 VGPRs) is the most that does not spill
+    static const int ldspad = env_int("UR_LIGHTING_LDSPAD", 0); // diagnostic: unused dynamic LDS to throttle workgroups per CU
+    if (waves >= 8) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 8>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
+    else if (waves == 7) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 7>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
+    else if (waves == 6) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
+    else hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 4>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
 }
 
 template <int MODE, bool SHADOWS>
