@@ -482,8 +482,8 @@ __device__ __forceinline__ PixelIn fetch_pixel(const LightingParams& p, uint32_t
     return q;
 }
 
-template <int MODE, bool SHADOWS, int TW>
-__global__ __launch_bounds__(256) void lighting_kernel_persistent(LightingParams p, uint32_t tilesX, uint32_t numTiles)
+template <int MODE, bool SHADOWS, int TW, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void lighting_kernel_persistent(LightingParams p, uint32_t tilesX, uint32_t numTiles)
 {
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the simple kernel");
     __shared__ float srgb[256];
@@ -557,7 +557,9 @@ void launch_tile_shape(ur_ctx* ctx, const LightingParams& p)
         static const int bpc = env_int("UR_LIGHTING_PERSISTENT", 0); // 0 = one workgroup per tile; N = N persistent workgroups per CU
         const uint32_t numTiles = tilesX * tilesY;
         if (bpc > 0 && numTiles > (uint32_t)(ctx->cu_count * bpc)) {
-            hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
+            if (bpc >= 6) hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW, 6>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
+            else if (bpc == 5) hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW, 5>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
+            else hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW, 4>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
             return;
         }
     }
