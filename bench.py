@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--ring", type=int, default=4, help="distinct frame-buffer sets cycled through so inputs are cache-cold")
     ap.add_argument("--cull-instances", type=int, default=1_000_000)
     ap.add_argument("--no-async", action="store_true", help="run the visibility passes on the main stream (no overlap with lighting)")
+    ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 1M-instance cull and iid side measurements")
     return ap.parse_args()
@@ -150,9 +151,14 @@ def main():
         s["res"] = Frame.resources(W, H, row0, band, s["A"], s["B"], s["C"], s["depth_band"], s["hdr_band"], s["depth_full"], hzb, lay, tables,
                                    d_bounds, d_args, i1 - i0, i0, d_vis, d_cnt, None)
 
+    # roofline leg: the Lighting pass of every timed frame is bracketed by a HIP event pair on the stream it is launched on
+    timed_flags = flags if args.no_light_events else (flags | urlib.UR_FRAME_TIME_LIGHTING)
+
     def step(k: int, timed: bool):
         s = sets[k % ring]
-        frame.render(s["res"], cull_consts, fc.scene, fc.sky, flags)
+        # one frame in eight carries the event pair: an event record costs ~4 us of queue time on this stack, which would
+        # otherwise inflate every timed frame by ~6 %
+        frame.render(s["res"], cull_consts, fc.scene, fc.sky, timed_flags if (timed and k % 8 == 0) else flags)
         if N > 1:
             urdist.allgather_hdr(s["hdr_full"], s["hdr_band"])
 
@@ -178,18 +184,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline leg: the dominant kernel alone on the same stream, HIP events around each launch (the frame's own kernels
-    # overlap across two streams, so per-launch duration is measured in a separate loop right after the timed region)
-    light_events = []
+    light_ms = frame.lighting_times_ms().astype(np.float64)  # inside the timed region, beside the async visibility passes
+    # the same kernel alone on the stream (no concurrent visibility passes), for reference
+    evs = []
     for k in range(min(args.steps, 100)):
         s = sets[k % ring]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         hp.deferred_lighting_sky(fc.scene, fc.sky, s["A"], s["B"], s["C"], s["depth_band"], tables, s["hdr_band"], W, H, row0, band)
         e1.record()
-        light_events.append((e0, e1))
+        evs.append((e0, e1))
     torch.cuda.synchronize()
-    light_ms = np.array([a.elapsed_time(b) for a, b in light_events], dtype=np.float64)
+    alone_ms = np.array([a.elapsed_time(b) for a, b in evs], dtype=np.float64)
+    if light_ms.size == 0:
+        light_ms = alone_ms
     n_sky = int((g.depth == 0).sum())
     n_geo = g.depth.size - n_sky
     # algorithmic bytes of one fused launch on this rank: geometry pixels read A 8 + B 8 + C 4 + depth 4 + HDR 8 and write
@@ -225,6 +233,8 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float(light_ms.min()) * 1e3,
             "shade_only_mpixels_per_s": g.depth.size * N / light_avg_s / 1e6,
+            "launches_sampled": int(light_ms.size), "alone_on_stream_us": float(alone_ms.mean()) * 1e3,
+            "alone_on_stream_frac": light_bytes / (float(alone_ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS,
         },
     }
     traffic_file = ROOT / "profiles" / "traffic_latest.json"

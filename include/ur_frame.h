@@ -49,6 +49,7 @@ typedef struct ur_frame_resources {
 #define UR_FRAME_ASYNC_COMPUTE 0x200u /* GPU Culling + Build HZB on a second HIP stream, overlapping Lighting/Sky */
 #define UR_FRAME_ASYNC_NO_JOIN 0x400u /* with ASYNC_COMPUTE: do not end the frame with a main<-async join; the caller calls ur_frame_join_async() */
 #define UR_FRAME_TONEMAP 0x800u /* add the Tonemap pass after Sky (Exposure 0.9, Gamma 2.2, PBR-neutral curve) */
+#define UR_FRAME_TIME_LIGHTING 0x1000u /* bracket the Lighting pass with a HIP event pair on its stream; read with ur_frame_lighting_times() */
 #define UR_FRAME_DEFAULT (UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY)
 
 ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size);
@@ -60,6 +61,9 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* res, const uint32_t* 
                     const ur_sky_constants* sky, uint32_t option_flags);
 /* Main stream waits for everything the async-compute stream has been given so far (see UR_FRAME_ASYNC_NO_JOIN). */
 void ur_frame_join_async(ur_frame* f);
+/* Elapsed milliseconds of the Lighting passes recorded since the last call (UR_FRAME_TIME_LIGHTING; up to 1024 kept).
+ * Call after the stream has been synchronised. Returns how many were written. */
+uint32_t ur_frame_lighting_times(ur_frame* f, float* out_ms, uint32_t cap);
 int ur_frame_hzb_ready(const ur_frame* f);
 void ur_frame_reset_hzb(ur_frame* f);
 /* Last execution: one line per pass "name|culled(0/1)|transitions|async(0/1)|cross-stream waits". Returns bytes needed (incl. NUL). */

@@ -119,8 +119,10 @@ int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Re
         if (Data.bUseShadows) Builder.ReadTexture(ShadowHandle, RG_STATE_PIXEL_SHADER_RESOURCE);
         if (Data.bFusedSky) Builder.ReadTexture(DepthHandle, RG_STATE_DEPTH_READ);
         Builder.WriteTexture(LightingHandle, RG_STATE_RENDER_TARGET);
-    }, [this, &Res](const FLightingPassData& Data, FHIPCommandContext& Cmd)
+    }, [this, &Res, &Options](const FLightingPassData& Data, FHIPCommandContext& Cmd)
     {
+        const bool bTimed = Options.bTimeLighting && LightingTimer;
+        if (bTimed) LightingTimer(Cmd.GetStream(), true);
         int rc;
         if (Data.bFusedSky)
             rc = ur_deferred_lighting_sky(Cmd.GetContext(), &Data.Scene, &Data.Sky, Res.GBufferA, Res.GBufferB, Res.GBufferC, Res.DepthBand, &Res.Tables,
@@ -128,6 +130,7 @@ int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Re
         else
             rc = ur_deferred_lighting(Cmd.GetContext(), &Data.Scene, Res.GBufferA, Res.GBufferB, Res.GBufferC, &Res.Tables, Res.LightingBand, Res.Width,
                                       Res.Height, Res.Row0, Res.Rows);
+        if (bTimed) LightingTimer(Cmd.GetStream(), false);
         if (rc != UR_OK && PassError == UR_OK) PassError = rc;
     });
 
@@ -191,6 +194,8 @@ struct ur_frame
     hipStream_t AsyncStream = nullptr;
     ur_ctx* AsyncCtx = nullptr;
     int DeviceIndex = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> LightEvents; // ring of event pairs around the Lighting pass
+    size_t LightHead = 0, LightCount = 0;
     ur_frame(ur_ctx* Ctx, hipStream_t Stream, uint32 Frames, int Rank, int World) : Cmd(Ctx, Stream, Frames, Rank, World), Renderer(&Device) {}
 };
 
@@ -199,7 +204,36 @@ extern "C" {
 ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size)
 {
     if (!ctx) return nullptr;
-    return new ur_frame(ctx, static_cast<hipStream_t>(stream), frames_in_flight, rank, world_size);
+    ur_frame* f = new ur_frame(ctx, static_cast<hipStream_t>(stream), frames_in_flight, rank, world_size);
+    f->Renderer.SetLightingTimer([f](hipStream_t s, bool begin) {
+        constexpr size_t kRing = 1024;
+        if (f->LightEvents.size() < kRing && begin && f->LightCount == f->LightEvents.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) f->LightEvents.emplace_back(a, b);
+        }
+        if (f->LightEvents.empty()) return;
+        if (begin) {
+            f->LightHead = f->LightCount % f->LightEvents.size();
+            (void)hipEventRecord(f->LightEvents[f->LightHead].first, s);
+        } else {
+            (void)hipEventRecord(f->LightEvents[f->LightHead].second, s);
+            ++f->LightCount;
+        }
+    });
+    return f;
+}
+
+uint32_t ur_frame_lighting_times(ur_frame* f, float* out_ms, uint32_t cap)
+{
+    if (!f) return 0;
+    const size_t n = f->LightCount < f->LightEvents.size() ? f->LightCount : f->LightEvents.size();
+    uint32_t k = 0;
+    for (size_t i = 0; i < n && k < cap; ++i) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, f->LightEvents[i].first, f->LightEvents[i].second) == hipSuccess) out_ms[k++] = ms;
+    }
+    f->LightCount = 0;
+    return k;
 }
 
 void ur_frame_destroy(ur_frame* f)
@@ -208,6 +242,7 @@ void ur_frame_destroy(ur_frame* f)
     if (f->AsyncStream) (void)hipStreamSynchronize(f->AsyncStream);
     if (f->AsyncCtx) ur_destroy(f->AsyncCtx);
     if (f->AsyncStream) (void)hipStreamDestroy(f->AsyncStream);
+    for (auto& e : f->LightEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete f;
 }
 
@@ -256,6 +291,7 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
         if (!f->AsyncCtx) return UR_EHIP;
         f->Cmd.SetAsyncCompute(f->AsyncCtx, f->AsyncStream);
     }
+    O.bTimeLighting = (flags & UR_FRAME_TIME_LIGHTING) != 0;
     O.bGpuTiming = (flags & UR_FRAME_GPU_TIMING) != 0;
     O.bGraphDump = (flags & UR_FRAME_GRAPH_DUMP) != 0;
     O.bBarrierLogs = (flags & UR_FRAME_BARRIER_LOGS) != 0;

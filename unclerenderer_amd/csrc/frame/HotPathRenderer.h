@@ -7,6 +7,7 @@
 // prepass, G-buffer raster, post FX) are out of scope: their outputs arrive as imported textures.
 #pragma once
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,7 @@ struct FHotPathOptions
     bool bFuseLightingAndSky = false; // MI355X fast path: one pass, same result as Lighting followed by Sky
     bool bTonemap = false;            // next row: Tonemap pass after Sky (TAA / auto exposure off)
     bool bAsyncCompute = false;       // MI355X: GPU Culling + Build HZB on the async-compute stream, overlapping Lighting
+    bool bTimeLighting = false;       // HIP event pair around the Lighting pass only (bench roofline leg), see SetLightingTimer
     bool bGpuTiming = false;
     bool bGraphDump = false;
     bool bBarrierLogs = false;
@@ -82,6 +84,9 @@ public:
     // error a pass reported. bHZBReady carries over between frames exactly like FDeferredRenderer::bHZBReady.
     int RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Res, const FHotPathFrameConstants& Constants, const FHotPathOptions& Options);
 
+    // Optional hook: called right before / after the Lighting pass launches, on the pass's stream (used by the frame
+    // object to bracket the dominant kernel with a HIP event pair without timing every pass).
+    void SetLightingTimer(std::function<void(hipStream_t, bool /*begin*/)> Fn) { LightingTimer = std::move(Fn); }
     bool IsHZBReady() const { return bHZBReady; }
     void ResetHZB() { bHZBReady = false; }
     const std::vector<FRenderGraph::FPassReport>& GetLastReport() const { return LastReport; }
@@ -91,4 +96,5 @@ private:
     bool bHZBReady = false;
     int PassError = 0;
     std::vector<FRenderGraph::FPassReport> LastReport;
+    std::function<void(hipStream_t, bool)> LightingTimer;
 };

@@ -179,6 +179,12 @@ class Frame:
         _lib.check(self._L.ur_frame_render(self._f, C.byref(res), cc.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(scene), C.byref(sky), flags),
                    "ur_frame_render")
 
+    def lighting_times_ms(self) -> np.ndarray:
+        """Durations of the Lighting passes bracketed with UR_FRAME_TIME_LIGHTING since the last call (synchronise first)."""
+        buf = np.zeros(1024, np.float32)
+        n = self._L.ur_frame_lighting_times(self._f, _lib.fptr(buf), 1024)
+        return buf[:n].copy()
+
     def join_async(self):
         self._L.ur_frame_join_async(self._f)
 
