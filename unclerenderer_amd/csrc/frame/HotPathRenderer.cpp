@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -286,7 +287,7 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     O.bAsyncCompute = (flags & UR_FRAME_ASYNC_COMPUTE) != 0;
     if (O.bAsyncCompute && !f->AsyncCtx) { // second stream + a context bound to it, created on first use
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithPriority(&f->AsyncStream, hipStreamNonBlocking, -1) != hipSuccess) return UR_EHIP; // high priority: its short kernels slot in beside the lighting kernel
+        if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithPriority(&f->AsyncStream, hipStreamNonBlocking, std::getenv("UR_ASYNC_PRIORITY") ? std::atoi(std::getenv("UR_ASYNC_PRIORITY")) : -1) != hipSuccess) return UR_EHIP; // default high priority: its short kernels slot in beside the lighting kernel
         f->AsyncCtx = ur_create(dev, f->AsyncStream);
         if (!f->AsyncCtx) return UR_EHIP;
         f->Cmd.SetAsyncCompute(f->AsyncCtx, f->AsyncStream);
