@@ -17,7 +17,9 @@
 
 #include "ur_internal.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -26,6 +28,25 @@ namespace {
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// The launch-uniform values one iteration of the streaming kernel reads, contiguous so that they arrive in a few wide
+// scalar loads at the top of the iteration.
+struct StreamHot {
+    uint32_t tilesX, numTiles, stepX, stepY, W, rows, row0, irrN0, irrRowBytes;
+    uint32_t ablate; // diagnostic (UR_LIGHTING_ABLATE): bit 0 no PCF math, 1 no cube filter, 2 no BRDF math, 3 no global gathers, 4 no LDS lookups
+    float invW2, invH2, invP11, nInvP22;      // ray: ra = ndc.x * invP11, rb = ndc.y * nInvP22 (= -1/P22)
+    float skyInvP11, nSkyInvP22, skyNearOverR2, maxMip;
+    float envMaxLevel, irrNf, irrEf, irrEEf, irrOfff; // irradiance mip: N, N+2, (N+2)^2, texel offset — as floats (exact)
+    float shadowWm3, shadowHm3, shadowWf;     // W-3, H-3, W as floats
+    float shadowXmax, shadowYmax, shadowStrength, shadowNegQuarterStrength; // W - 0.5, H - 0.5, s, -s/4
+    uint32_t shadowRowBytes;
+    int32_t shadowWi, shadowHi;
+    const void* env;
+    const float* shadow;
+    void* hdr;
+    float R[9], L[3], lightRGB[3];
+    float shX[4], shY[4], shZ[4];     // su * W - 0.5 = viewZ * (ra * shX[0] + rb * shX[1] + shX[2]) + shX[3], ...; shZ: depth - bias
+};
 
 struct LightingParams {
     // frame
@@ -55,6 +76,7 @@ struct LightingParams {
     float skyScatterR[3];// rayleighColor * rayleighDensity * 3/(16 pi)
     float skyMie[3];     // LightColor * mieDensity * 0.8 * (1-g^2)/(4 pi)
     float sunAttenuation;
+    StreamHot hot;       // streaming kernel: everything one loop iteration reads
     // buffers
     const half4_t* A;
     const half4_t* B;
@@ -74,19 +96,38 @@ __device__ __forceinline__ float mix(float a, float b, float t) { return fmaf(t,
 
 // base + 32-bit unsigned BYTE offset: lets the compiler use the SGPR-base + VGPR-offset addressing mode of global_load
 // instead of 64-bit VALU address arithmetic (v_lshl_add_u64 per access).
+// (The pointers are global memory by contract; saying so keeps pointers that were themselves loaded from memory off the
+// flat_load path.)
+#define UR_GLOBAL __attribute__((address_space(1)))
 template <class T>
 __device__ __forceinline__ T ld(const void* base, uint32_t byte_offset)
 {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
+    return *reinterpret_cast<const UR_GLOBAL T*>((const UR_GLOBAL char*)base + byte_offset);
 }
 template <class T>
 __device__ __forceinline__ void st(void* base, uint32_t byte_offset, T v)
 {
-    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_offset) = v;
+    *reinterpret_cast<UR_GLOBAL T*>((UR_GLOBAL char*)base + byte_offset) = v;
 }
 
-struct __attribute__((packed, aligned(8))) uint4u { uint32_t x, y, z, w; }; // 16 bytes, 8-byte aligned
-struct __attribute__((packed, aligned(4))) float3u { float x, y, z; };      // 12 bytes, 4-byte aligned
+struct uint4u { uint32_t x, y, z, w; };  // 16 bytes loaded from an 8-byte-aligned address
+struct float3u { float x, y, z; };       // 12 bytes loaded from a 4-byte-aligned address
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x3_t __attribute__((ext_vector_type(3)));
+typedef u32x4_t u32x4_a8 __attribute__((aligned(8)));
+typedef f32x3_t f32x3_a4 __attribute__((aligned(4)));
+template <>
+__device__ __forceinline__ uint4u ld<uint4u>(const void* base, uint32_t byte_offset)
+{
+    const u32x4_t v = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)base + byte_offset);
+    return {v.x, v.y, v.z, v.w};
+}
+template <>
+__device__ __forceinline__ float3u ld<float3u>(const void* base, uint32_t byte_offset)
+{
+    const f32x3_t v = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)base + byte_offset);
+    return {v.x, v.y, v.z};
+}
 
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { return {x, y, z}; }
@@ -259,18 +300,31 @@ __device__ __noinline__ float shadow_pcf_border(const float* __restrict__ map, i
     return 0.25f * acc;
 }
 
-// DeferredLighting.hlsl:35-94 for one pixel. (a,b) = camera ray (ndc.x/P11, -ndc.y/P22); viewPos = viewZ * (a, b, 1).
-template <class T, class = void> struct ur_has_fence { static constexpr bool value = true; };
-template <class T> struct ur_has_fence<T, std::void_t<decltype(std::decay_t<T>::kFence)>> { static constexpr bool value = std::decay_t<T>::kFence; };
-struct NoPrefetch { static constexpr bool kFence = false; __device__ __forceinline__ void operator()() const {} };
+// the same, inlined (the streaming kernel keeps no call in its loop: a call pins live values to callee-saved registers)
+__device__ __forceinline__ float shadow_pcf_border_inline(const float* __restrict__ map, int W, int H, int ia, int ja, float fx, float fy, float cmp)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float s = 0.0f;
+        const int yj = ja + r;
+        const uint32_t rowo = (uint32_t)min(max(yj, 0), H - 1) * (uint32_t)W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int xi = ia + c;
+            const bool in = (uint32_t)xi < (uint32_t)W && (uint32_t)yj < (uint32_t)H;
+            const float t = ld<float>(map, (rowo + (uint32_t)min(max(xi, 0), W - 1)) * 4u);
+            s += (in ? cmp <= t : true) ? (c == 0 ? 1.0f - fx : (c == 1 ? 1.0f : fx)) : 0.0f;
+        }
+        acc = fmaf(r == 0 ? 1.0f - fy : (r == 1 ? 1.0f : fy), s, acc);
+    }
+    return 0.25f * acc;
+}
 
-// `mipOffset`: the per-mip texel offsets (LDS copy in the persistent kernel: a per-lane indexed read of the kernarg copy is
-// a dependent global load in front of the cube gathers). `after_gathers` runs once every gather of this pixel has been
-// issued and before their results are consumed: loads issued inside it are YOUNGER than the gathers, so the waits on the
-// gathers (in-order vmcnt) do not wait for them — that is where the persistent kernel prefetches the next tile.
-template <bool SHADOWS, class AfterGathers>
+// DeferredLighting.hlsl:35-94 for one pixel. (a,b) = camera ray (ndc.x/P11, -ndc.y/P22); viewPos = viewZ * (a, b, 1).
+template <bool SHADOWS>
 __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* srgb, const uint32_t* mipOffset, float ra, float rb, half4_t ga, half4_t gb,
-                                          uint32_t gc, AfterGathers&& after_gathers)
+                                          uint32_t gc)
 {
     // ---- decode, view vectors ------------------------------------------------------------------------------------------
     const float nx = (float)ga.x, ny = (float)ga.y, nz = (float)ga.z;
@@ -319,13 +373,6 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
         sh = shadow_taps_load(p, su, sv);
     }
     const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
-    if constexpr (ur_has_fence<AfterGathers>::value) {
-        __builtin_amdgcn_sched_barrier(0); // keep the prefetch loads behind the gathers in issue order
-        after_gathers();
-        __builtin_amdgcn_sched_barrier(0);
-    } else {
-        after_gathers();
-    }
 
     // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) --------------------------------------------
     const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
@@ -386,24 +433,26 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
 }
 
 // SkyAtmosphere.hlsl:58-93 with the camera-height densities, phase constants and sun attenuation folded on the host.
-__device__ __forceinline__ F3 sky_pixel(const LightingParams& p, float vx, float vy)
+// P: pointer to the parameters (generic for the per-tile kernel; a re-read kernarg pointer in the streaming kernel)
+template <class P>
+__device__ __forceinline__ F3 sky_pixel(P p, float vx, float vy)
 {
-    const float* Q = p.skyRot;
+    const auto* Q = p->skyRot;
     F3 w = f3(fmaf(vy, Q[1], fmaf(vx, Q[0], Q[2])), fmaf(vy, Q[4], fmaf(vx, Q[3], Q[5])), fmaf(vy, Q[7], fmaf(vx, Q[6], Q[8])));
     const float wr = rsq(dot(w, w));
     w = f3(w.x * wr, w.y * wr, w.z * wr);
     const float h = 1.0f - sat(fmaf(w.y, 0.5f, 0.5f));
     const float falloff = sat(h * h * h);
-    const float cosSunView = dot(w, f3(p.sunDir[0], p.sunDir[1], p.sunDir[2]));
+    const float cosSunView = dot(w, f3(p->sunDir[0], p->sunDir[1], p->sunDir[2]));
     const float rayleighPhase = fmaf(cosSunView, cosSunView, 1.0f);
     const float g = 0.76f, g2 = g * g;
     const float mb = fmaf(-2.0f * g, cosSunView, 1.0f + g2);
     const float denom = mb * __builtin_amdgcn_sqrtf(mb); // pow(x, 1.5)
     const float miePhase = rcp(fmaxf(denom, 1e-3f));
     F3 c;
-    c.x = fmaf(fmaf(p.skyMie[0], miePhase, p.skyScatterR[0] * rayleighPhase), p.sunAttenuation, mix(0.05f, 0.52f, falloff));
-    c.y = fmaf(fmaf(p.skyMie[1], miePhase, p.skyScatterR[1] * rayleighPhase), p.sunAttenuation, mix(0.12f, 0.68f, falloff));
-    c.z = fmaf(fmaf(p.skyMie[2], miePhase, p.skyScatterR[2] * rayleighPhase), p.sunAttenuation, mix(0.22f, 0.86f, falloff));
+    c.x = fmaf(fmaf(p->skyMie[0], miePhase, p->skyScatterR[0] * rayleighPhase), p->sunAttenuation, mix(0.05f, 0.52f, falloff));
+    c.y = fmaf(fmaf(p->skyMie[1], miePhase, p->skyScatterR[1] * rayleighPhase), p->sunAttenuation, mix(0.12f, 0.68f, falloff));
+    c.z = fmaf(fmaf(p->skyMie[2], miePhase, p->skyScatterR[2] * rayleighPhase), p->sunAttenuation, mix(0.22f, 0.86f, falloff));
     return c;
 }
 
@@ -431,7 +480,7 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
         const float len = __builtin_amdgcn_sqrtf(fmaf(vx, vx, fmaf(vy, vy, 1.0f)));
         const float skyDepth = p.skyNearOverR * len; // Near / (R * unit_dir.z), unit_dir.z = 1/len
         if (skyDepth >= ld<float>(p.depth, i * 4u)) {
-            const F3 sky = sky_pixel(p, vx, vy);
+            const F3 sky = sky_pixel(&p, vx, vy);
             half4_t o;
             o.x = (_Float16)sky.x; o.y = (_Float16)sky.y; o.z = (_Float16)sky.z; o.w = (_Float16)1.0f;
             st<half4_t>(p.hdr, i * 8u, o);
@@ -442,7 +491,7 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
     const half4_t ga = ld<half4_t>(p.A, i * 8u), gb = ld<half4_t>(p.B, i * 8u);
     const uint32_t gc = ld<uint32_t>(p.C, i * 4u);
     const half4_t d = ld<half4_t>(p.hdr, i * 8u);
-    const F3 col = shade_pixel<SHADOWS>(p, srgb, p.envMipOffset, ndcx * p.invP11, -ndcy * p.invP22, ga, gb, gc, NoPrefetch{});
+    const F3 col = shade_pixel<SHADOWS>(p, srgb, p.envMipOffset, ndcx * p.invP11, -ndcy * p.invP22, ga, gb, gc);
     half4_t o;
     o.x = (_Float16)((float)d.x + col.x);
     o.y = (_Float16)((float)d.y + col.y);
@@ -451,85 +500,450 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
     st<half4_t>(p.hdr, i * 8u, o);
 }
 
-// Persistent form of the same kernel: workgroups loop over 64x4-pixel tiles (stride gridDim.x) and issue the NEXT
-// tile's streaming G-buffer loads before shading the current one, so HBM latency hides under ~500 VALU instructions
-// instead of relying on occupancy alone; the sRGB table is staged into LDS once per workgroup instead of once per tile.
-struct PixelIn {
-    half4_t a, b, d;
-    uint32_t c;
-    float depth;
-    uint32_t i, px, py;
-    bool valid;
-};
+// =====================================================================================================================
+// Streaming form (the default for full-tile regions): persistent waves, each looping over 16x4-pixel tiles.
+//
+//  * G-buffer tiles arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR destination) into a wave-private double buffer,
+//    two tiles ahead: the HBM latency of the streaming reads is never exposed and costs no registers. Two DMA
+//    instructions move a whole tile (A|B and HDR|C|depth: the per-lane SOURCE address selects the buffer, the LDS image
+//    is lane-linear), so pixel p of the tile sits at a fixed LDS offset per buffer.
+//  * Ordering protocol (the DMA is invisible to hipcc's s_waitcnt bookkeeping): in iteration t the DMA for tile t+2 is
+//    issued into the buffer tile t was read from, at a point where hipcc has no pending load of its own (every gather
+//    result has been touched by an asm statement, so its waits sit in front of that point). The wait for iteration
+//    t+1's gathers is a vmcnt(0) by construction (hipcc sees nothing younger), which also retires the DMA for tile t+2
+//    one full iteration after its issue — before iteration t+2 reads it. No counted waits, no barriers in the loop.
+//  * The BRDF LUT lives in LDS as bordered fp32 pairs (clamp addressing = border texels; one med3 instead of eight
+//    min/max, no unpack/convert per tap), the launch-uniform irradiance mip as fp32 texels, the sRGB table as before.
+//  * The shadow transform of the (orthographic) light is folded on the host into three affine forms of the camera ray.
+// =====================================================================================================================
+constexpr uint32_t kLutW = 128, kLutH = 32, kLutE = kLutW + 2;    // streaming kernel: LUT dimensions are compile-time
+constexpr uint32_t kLdsSrgb = 0;                                    // 256 floats
+constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
+constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // up to 6 * 4 * 4 float4 (irradiance mip, N <= 2)
+constexpr uint32_t kLdsLut = kLdsIrr + 6 * 16 * 16;                 // (kLutW + 2) x (kLutH + 2) float2
+constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
+constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
+static_assert(kLdsTiles % 16 == 0, "tile buffers are 16-byte aligned");
 
-template <int MODE, int TW>
-__device__ __forceinline__ PixelIn fetch_pixel(const LightingParams& p, uint32_t tile, uint32_t tilesX, uint32_t lane, uint32_t wave)
+__device__ __forceinline__ uint32_t lds_address(const void* p)
 {
-    constexpr int TH = 64 / TW;
-    PixelIn q;
-    const uint32_t ty = tile / tilesX, tx = tile - ty * tilesX; // uniform: scalar ALU
-    q.px = (tx * 4u + wave) * TW + (lane % TW);
-    const uint32_t r = ty * TH + (lane / TW);
-    q.valid = q.px < p.W && r < p.rows;
-    q.py = p.row0 + r;
-    q.i = r * p.W + q.px;
-    const uint32_t i = q.valid ? q.i : 0u;
-    if (MODE != ur::UR_MODE_LIGHTING) q.depth = ld<float>(p.depth, i * 4u);
-    q.a = ld<half4_t>(p.A, i * 8u);
-    q.b = ld<half4_t>(p.B, i * 8u);
-    q.c = ld<uint32_t>(p.C, i * 4u);
-    q.d = ld<half4_t>(p.hdr, i * 8u);
-    return q;
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
-template <int MODE, bool SHADOWS, int TW, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void lighting_kernel_persistent(LightingParams p, uint32_t tilesX, uint32_t numTiles)
+// One LDS-DMA wave-instruction: lane l's 16 bytes at gsrc land at lds_dst + 16 l. M0 is saved and restored (it is
+// compiler-reserved and not preserved around asm statements).
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst_uniform)
 {
-    static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the simple kernel");
-    __shared__ float srgb[256];
-    __shared__ uint32_t mipOffset[16];
-    srgb[threadIdx.x] = p.srgb[threadIdx.x];
-    if (threadIdx.x < 16u) mipOffset[threadIdx.x] = p.envMipOffset[threadIdx.x];
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
+}
+
+struct TileSrc { const char* p1; const char* p2; uint32_t mul2; }; // per-lane source bases of the two DMA instructions
+
+// Kernel parameters re-read from the kernarg segment (scalar loads) behind an opaque pointer: hipcc would otherwise hoist
+// every parameter out of the persistent loop and spill the ~150 live scalars to VGPR lanes.
+typedef const __attribute__((address_space(4))) LightingParams* KParams;
+__device__ __forceinline__ KParams fresh_params()
+{
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return (KParams)k; // LightingParams is the kernel's only argument: offset 0
+}
+
+// maxRow = last valid row of the tile (3 for a whole tile): the rows of a partial bottom tile re-read the last valid one
+template <int MODE, class P>
+__device__ __forceinline__ TileSrc tile_src(P p, uint32_t lane, uint32_t maxRow)
+{
+    TileSrc s;
+    const uint32_t W = p->W;
+    const uint32_t q = lane & 31u, r8 = min(q >> 3, maxRow), c8 = (q & 7u) * 2u;     // 8-byte-per-pixel buffers: 2 pixels per lane
+    const uint32_t q4 = lane & 15u, r4 = min(q4 >> 2, maxRow), c4 = (q4 & 3u) * 4u;  // 4-byte-per-pixel buffers: 4 pixels per lane
+    const uint64_t o8 = (uint64_t)(r8 * W + c8) * 8u, o4 = (uint64_t)(r4 * W + c4) * 4u;
+    const char* A = reinterpret_cast<const char*>(p->A);
+    const char* B = reinterpret_cast<const char*>(p->B);
+    const char* C = reinterpret_cast<const char*>(p->C);
+    const char* D = reinterpret_cast<const char*>(p->depth);
+    const char* H = reinterpret_cast<const char*>(p->hdr);
+    s.p1 = (lane < 32u ? A : B) + o8;
+    if (lane < 32u) { s.p2 = H + o8; s.mul2 = 8u; }
+    else if (lane < 48u || MODE == ur::UR_MODE_LIGHTING) { s.p2 = C + o4; s.mul2 = 4u; }
+    else { s.p2 = D + o4; s.mul2 = 4u; }
+    return s;
+}
+
+__device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pixel index of the tile's first pixel*/, uint32_t lds_dst)
+{
+    dma16(s.p1 + (uint64_t)origin * 8u, lds_dst);
+    dma16(s.p2 + (uint64_t)origin * s.mul2, lds_dst + 1024u);
+}
+
+// tile (tx, ty) -> LDS; `full` = the precomputed per-lane sources of a whole tile
+template <int MODE, class P>
+__device__ __forceinline__ void tile_prefetch(P p, uint32_t W, uint32_t rows, const TileSrc& full, uint32_t lane, uint32_t tx, uint32_t ty, uint32_t lds_dst)
+{
+    const uint32_t origin = (ty * 4u) * W + tx * 16u, rowsLeft = rows - ty * 4u; // uniform
+    if (rowsLeft >= 4u) tile_dma(full, origin, lds_dst);
+    else tile_dma(tile_src<MODE>(p, lane, rowsLeft - 1u), origin, lds_dst);
+}
+
+// One iteration's copy of the hot block (a handful of wide scalar loads).
+struct HotView {
+    StreamHot h;
+    __device__ __forceinline__ explicit HotView(KParams kp)
+    {
+        constexpr uint32_t n = sizeof(StreamHot) / 4u;
+        const __attribute__((address_space(4))) uint32_t* src = reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(&kp->hot);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&h);
+#pragma unroll
+        for (uint32_t i = 0; i < n; ++i) dst[i] = src[i];
+    }
+    __device__ __forceinline__ const StreamHot* operator->() const { return &h; }
+};
+
+struct __attribute__((aligned(16))) float4a { float x, y, z, w; };
+
+// A launch-uniform value pinned in a VGPR (a VOP3 instruction reads at most one SGPR: the second uniform operand of an FMA
+// would otherwise cost a v_mov per use and per iteration).
+__device__ __forceinline__ float vreg(float uniform)
+{
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform));
+    return v;
+}
+
+// fp16 halves of a packed dword -> fp32 behind an opaque conversion: hipcc would otherwise fold the conversions into
+// v_fma_mix_f32 / SDWA forms, which hold the VALU issue port for 4-6 cycles on gfx950 (tools/microbench/valu_rate4.hip)
+// where a plain v_cvt on the side pipe overlaps with the FMAs around it.
+__device__ __forceinline__ float h2f_lo(uint32_t w)
+{
+    float r;
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(w));
+    return r;
+}
+__device__ __forceinline__ float h2f_hi(uint32_t w) { return h2f_lo(w >> 16); }
+
+// g = (cmp > t) as clamp(cmp * 2^126 - t * 2^126): one clamped FMA per tap (cmpBig = cmp * 2^126 is exact), exact for every
+// finite pair; equality gives 0 (LESS_EQUAL passes).
+__device__ __forceinline__ float gt_step(float cmpBig, float t, float negBig /* -2^126 in a VGPR */)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(t), "v"(negBig), "v"(cmpBig));
+    return r;
+}
+
+struct __attribute__((aligned(16))) MipEntry { float Nf, Ef, EEf, offf; uint32_t rowBytes, pad0, pad1, pad2; };
+constexpr uint32_t kLdsMipBytes = 17 * 32; // 16 mips + the duplicated last entry
+
+// input-only "these registers are needed here": hipcc puts the s_waitcnt of pending loads in front of the statement
+__device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u32x4_t& c, const u32x4_t& d)
+{
+    asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d));
+}
+
+// WPB waves per workgroup; WPB = 10 runs two workgroups per CU (5 waves/SIMD, 96 VGPRs), the others one.
+template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
+__global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_kernel(LightingParams p)
+{
+    static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the per-tile kernel");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* srgb = reinterpret_cast<float*>(smem + kLdsSrgb);
+    MipEntry* mipT = reinterpret_cast<MipEntry*>(smem + kLdsMip);
+    float4a* irrT = reinterpret_cast<float4a*>(smem + kLdsIrr);
+    float2* lut = reinterpret_cast<float2*>(smem + kLdsLut);
+
+    // ---- stage the tables (once per workgroup) ----------------------------------------------------------------------
+    for (uint32_t i = threadIdx.x; i < 256u; i += 64 * WPB) srgb[i] = p.srgb[i];
+    if (threadIdx.x < 17u) {
+        const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
+        const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
+        mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * E), (float)p.envMipOffset[m], E * 8u, 0u, 0u, 0u};
+    }
+    for (uint32_t i = threadIdx.x; i < kLutE * (kLutH + 2u); i += 64 * WPB) {
+        const uint32_t by = i / kLutE, bx = i - by * kLutE;
+        const uint32_t sx = min(max(bx, 1u), kLutW) - 1u, sy = min(max(by, 1u), kLutH) - 1u; // border = clamp addressing
+        const uint32_t t = p.lut[sy * kLutW + sx];
+        lut[i] = float2{(float)(t & 0xFFFFu) / 65535.0f, (float)(t >> 16) / 65535.0f};     // the oracle's texel values
+    }
+    if (IRR_LDS) {
+        const uint32_t E = p.irrN0 + 2u, n = 6u * E * E;
+        for (uint32_t i = threadIdx.x; i < n; i += 64 * WPB) {
+            const half4_t h = p.env[p.irrOffset0 + i];
+            irrT[i] = float4a{(float)h.x, (float)h.y, (float)h.z, 0.0f};
+        }
+    }
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t tile = blockIdx.x;
-    if (tile >= numTiles) return;
-    PixelIn cur = fetch_pixel<MODE, TW>(p, tile, tilesX, lane, wave);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform by construction: keeps the tile walk on the scalar ALU
+    const uint32_t G = gridDim.x * WPB;
+    uint32_t tile = blockIdx.x * WPB + wave;
+    if (tile >= p.hot.numTiles) return; // no barrier below
+    // tile -> (tx, ty) once by division, then incrementally (scalar ALU only)
+    uint32_t ty = tile / p.hot.tilesX, tx = tile - ty * p.hot.tilesX;
+    const uint32_t col = lane & 15u, row = lane >> 4;
+    const TileSrc src = tile_src<MODE>(&p, lane, 3u);
+    const uint32_t bufBase = __builtin_amdgcn_readfirstlane(lds_address(smem + kLdsTiles + wave * (2u * kTileBytes)));
+    const unsigned char* myTiles = smem + kLdsTiles + wave * (2u * kTileBytes);
+    // per-lane part of the pixel's NDC (the tile origin is added per iteration), and the few uniforms that appear as the
+    // SECOND scalar operand of an FMA
+    const float ndcxL = fmaf((float)col, p.invW2, 0.5f * p.invW2 - 1.0f);
+    const float rowh = (float)row + 0.5f; // ndc.y = (py + 0.5) * 2/H - 1 with py = row0 + 4 ty + row summed exactly: a band and the whole frame agree bit for bit
+    const float shX2 = vreg(p.hot.shX[2]), shY2 = vreg(p.hot.shY[2]), shZ2 = vreg(p.hot.shZ[2]);
+    const float negBig = vreg(-0x1p126f);
+
+    // ---- prologue: tiles t and t+G in flight, wait for both --------------------------------------------------------------
+    tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
+    uint32_t tx1 = tx + p.hot.stepX, ty1 = ty + p.hot.stepY;
+    if (tx1 >= p.hot.tilesX) { tx1 -= p.hot.tilesX; ty1 += 1u; }
+    if (tile + G < p.hot.numTiles) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    uint32_t parity = 0;
     for (;;) {
-        const uint32_t next = tile + gridDim.x;
-        const bool more = next < numTiles; // uniform
-        // The prefetch is issued unconditionally (the last iteration re-reads its own tile): a branch around it would
-        // make the compiler's s_waitcnt bookkeeping assume "no younger loads" and wait vmcnt(0) on the gathers.
-        const uint32_t pf = more ? next : tile;
-        PixelIn nxt;
-        const float ndcx = fmaf((float)cur.px + 0.5f, p.invW2, -1.0f);
-        const float ndcy = fmaf((float)cur.py + 0.5f, p.invH2, -1.0f);
+        // every launch-uniform value of the iteration in a few wide scalar loads
+        const KParams kp = fresh_params();
+        HotView q(kp);
+        // (tx2, ty2) = the tile two steps ahead (prefetched in this iteration)
+        uint32_t tx2 = tx1 + q->stepX, ty2 = ty1 + q->stepY;
+        if (tx2 >= q->tilesX) { tx2 -= q->tilesX; ty2 += 1u; }
+        const bool more2 = tile + 2u * G < q->numTiles; // uniform
+        const unsigned char* buf = myTiles + parity * kTileBytes;
+        const uint2 ga = *reinterpret_cast<const uint2*>(buf + lane * 8u);          // (nx, ny), (nz, -viewZ)
+        const uint2 gb = *reinterpret_cast<const uint2*>(buf + 512u + lane * 8u);   // (specular, metallic), (roughness, 1)
+        const uint2 gd = *reinterpret_cast<const uint2*>(buf + 1024u + lane * 8u);  // HDR in
+        const uint32_t gc = *reinterpret_cast<const uint32_t*>(buf + 1536u + lane * 4u);
+        const float ndcx = fmaf((float)(tx * 16u), q->invW2, ndcxL), ndcy = fmaf((float)(q->row0 + ty * 4u) + rowh, q->invH2, -1.0f);
+
         bool sky = false;
         F3 out = f3(0.0f, 0.0f, 0.0f);
         if (MODE == ur::UR_MODE_FUSED) {
-            const float vx = ndcx * p.skyInvP11, vy = -ndcy * p.skyInvP22;
-            const float len = __builtin_amdgcn_sqrtf(fmaf(vx, vx, fmaf(vy, vy, 1.0f)));
-            sky = p.skyNearOverR * len >= cur.depth;
-            if (sky) out = sky_pixel(p, vx, vy);
+            const float depth = *reinterpret_cast<const float*>(buf + 1792u + lane * 4u);
+            const float vx = ndcx * q->skyInvP11, vy = ndcy * q->nSkyInvP22;
+            // sphere depth (Near/R) * |(vx, vy, 1)| >= depth, compared squared (depth is in [0,1]): no square root
+            sky = q->skyNearOverR2 * fmaf(vx, vx, fmaf(vy, vy, 1.0f)) >= depth * depth;
+            if (sky) out = sky_pixel(kp, vx, vy);
         }
-        // Shade when any lane of the wave has geometry (wave-uniform branch, so the prefetch inside runs for every lane);
-        // sky / out-of-frame lanes compute on whatever they loaded and their result is dropped.
-        if (__any(cur.valid && !sky)) {
-            const F3 col = shade_pixel<SHADOWS>(p, srgb, mipOffset, ndcx * p.invP11, -ndcy * p.invP22, cur.a, cur.b, cur.c,
-                                                [&] { nxt = fetch_pixel<MODE, TW>(p, pf, tilesX, lane, wave); });
-            if (!sky) out = f3((float)cur.d.x + col.x, (float)cur.d.y + col.y, (float)cur.d.z + col.z);
+        float outw = 1.0f;
+        if (__any(!sky)) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
+            const float ra = ndcx * q->invP11, rb = ndcy * q->nInvP22;
+            // ---- decode, view vectors ----------------------------------------------------------------------------------------
+            const float nx = h2f_lo(ga.x), ny = h2f_hi(ga.x), nz = h2f_lo(ga.y), wv = h2f_hi(ga.y);
+            const float nr = rsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx))); // normalize(0) = NaN, as in the reference
+            const F3 N = f3(nx * nr, ny * nr, nz * nr);
+            const float viewZ = -wv;
+            const float spec0 = h2f_lo(gb.x), metallic = h2f_hi(gb.x), roughness = h2f_lo(gb.y);
+            // V = normalize(-viewPos) = -sign(viewZ) (ra, rb, 1) / |(ra, rb, 1)|; sign(-viewZ) is the stored sign of A.w
+            const float vs = __builtin_copysignf(rsq(fmaf(ra, ra, fmaf(rb, rb, 1.0f))), wv);
+            const F3 V = f3(ra * vs, rb * vs, vs);
+            const F3 L = f3(q->L[0], q->L[1], q->L[2]);
+            const float NdotVraw = dot(N, V);
+            const float NdotV = sat(NdotVraw);
+            const float NdotL = sat(dot(N, L));
+            // ---- global gathers: the two prefiltered mips (bordered cube, addresses in fp32: every integer multiply would hold
+            //      the issue port), then the shadow block ------------------------------------------------------------------------
+            const float t2 = 2.0f * NdotVraw;
+            const F3 Rw = rot(f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z)), q->R);
+            const float lvl = __builtin_amdgcn_fmed3f(roughness * q->maxMip, 0.0f, q->envMaxLevel);
+            const float fl = __builtin_amdgcn_fractf(lvl);
+            const MipEntry* me = mipT + (uint32_t)lvl;
+            const float4a e0 = *reinterpret_cast<const float4a*>(me), e1 = *reinterpret_cast<const float4a*>(me + 1);
+            const uint32_t rowB0 = me[0].rowBytes, rowB1 = me[1].rowBytes;
+            const float faceR = __builtin_amdgcn_cubeid(Rw.x, Rw.y, Rw.z);
+            const float invR = rcp(fabsf(__builtin_amdgcn_cubema(Rw.x, Rw.y, Rw.z)));
+            const float uR = fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
+            const float vR = fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
+            const void* env = q->env;
+            u32x4_t p0a = {0, 0, 0, 0}, p0b = p0a, p1a = p0a, p1b = p0a;
+            float fx0 = 0.0f, fy0 = 0.0f, fx1 = 0.0f, fy1 = 0.0f;
+            const uint32_t ablate = q->ablate;
+            if (!(ablate & 8u)) {
+            {
+                const float x = fmaf(uR, e0.x, 0.5f), y = fmaf(vR, e0.x, 0.5f); // bordered coordinates in [0.5, N + 0.5]
+                const float i0 = floorf(x), j0 = floorf(y);
+                fx0 = x - i0; fy0 = y - j0;
+                const uint32_t o = (uint32_t)(fmaf(faceR, e0.z, fmaf(j0, e0.y, i0)) + e0.w) * 8u;
+                p0a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
+                p0b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB0));
+            }
+            {
+                const float x = fmaf(uR, e1.x, 0.5f), y = fmaf(vR, e1.x, 0.5f);
+                const float i0 = floorf(x), j0 = floorf(y);
+                fx1 = x - i0; fy1 = y - j0;
+                const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 8u;
+                p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
+                p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB1));
+            }
+            }
+            const F3 Nw = rot(N, q->R);
+            const float faceN = __builtin_amdgcn_cubeid(Nw.x, Nw.y, Nw.z);
+            const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nw.x, Nw.y, Nw.z)));
+            const float uN = fmaf(__builtin_amdgcn_cubesc(Nw.x, Nw.y, Nw.z), invN, 0.5f);
+            const float vN = fmaf(__builtin_amdgcn_cubetc(Nw.x, Nw.y, Nw.z), invN, 0.5f);
+            u32x4_t pia = {0, 0, 0, 0}, pib = {0, 0, 0, 0};
+            float fxi = 0.0f, fyi = 0.0f;
+            if (!IRR_LDS) {
+                const float x = fmaf(uN, q->irrNf, 0.5f), y = fmaf(vN, q->irrNf, 0.5f);
+                const float i0 = floorf(x), j0 = floorf(y);
+                fxi = x - i0; fyi = y - j0;
+                const uint32_t o = (uint32_t)(fmaf(faceN, q->irrEEf, fmaf(j0, q->irrEf, i0)) + q->irrOfff) * 8u;
+                pia = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
+                pib = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + q->irrRowBytes));
+            }
+            // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF (direct = 0).
+            const bool wave_lit = SHADOWS && __any(NdotL > 0.0f) && !(ablate & 8u);
+            f32x3_t sa = {0, 0, 0}, sb = {0, 0, 0}, sc3 = {0, 0, 0};
+            float xa = 0.0f, ya = 0.0f, cmp = 0.0f, sfx = 0.0f, sfy = 0.0f;
+            bool fast = true;
+            if (wave_lit) {
+                // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) are affine in viewZ * (ra, rb, 1)
+                xa = fmaf(viewZ, fmaf(rb, q->shX[1], fmaf(ra, q->shX[0], shX2)), q->shX[3]);
+                ya = fmaf(viewZ, fmaf(rb, q->shY[1], fmaf(ra, q->shY[0], shY2)), q->shY[3]);
+                cmp = fmaf(viewZ, fmaf(rb, q->shZ[1], fmaf(ra, q->shZ[0], shZ2)), q->shZ[3]);
+                const float xa0 = floorf(xa), ya0 = floorf(ya);
+                sfx = xa - xa0; sfy = ya - ya0;
+                // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
+                const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, q->shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, q->shadowHm3);
+                fast = ic == xa0 && jc == ya0;
+                const uint32_t o0 = (uint32_t)fmaf(jc, q->shadowWf, ic) * 4u, o1 = o0 + q->shadowRowBytes, o2 = o1 + q->shadowRowBytes;
+                const float* smap = q->shadow;
+                sa = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o0);
+                sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
+                sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
+            }
+            // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
+            F3 albedo = f3(0.5f, 0.5f, 0.5f);
+            float ba = 0.5f, bb = 0.1f;
+            if (!(ablate & 16u)) {
+                albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
+                // bordered coordinates: x in [0.5, W + 0.5] (NdotV is saturated), y clamped likewise (roughness is not)
+                const float x = fmaf(NdotV, (float)kLutW, 0.5f);
+                const float y = __builtin_amdgcn_fmed3f(fmaf(roughness, (float)kLutH, 0.5f), 0.5f, (float)kLutH + 0.5f);
+                const float i0 = floorf(x), j0 = floorf(y);
+                const float fx = x - i0, fy = y - j0;
+                const float2* t = lut + (uint32_t)fmaf(j0, (float)kLutE, i0);
+                const float2 t00 = t[0], t10 = t[1], t01 = t[kLutE], t11 = t[kLutE + 1];
+                const float wy0 = 1.0f - fy;
+                const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
+                ba = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
+                bb = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
+            }
+            F3 irradiance = f3(0.0f, 0.0f, 0.0f);
+            if (IRR_LDS && !(ablate & 16u)) {
+                const float x = fmaf(uN, q->irrNf, 0.5f), y = fmaf(vN, q->irrNf, 0.5f);
+                const float i0 = floorf(x), j0 = floorf(y);
+                const float fx = x - i0, fy = y - j0;
+                const uint32_t E = q->irrN0 + 2u;
+                const float4a* t = irrT + (uint32_t)fmaf(faceN, q->irrEEf, fmaf(j0, q->irrEf, i0));
+                const float4a t00 = t[0], t10 = t[1], t01 = t[E], t11 = t[E + 1];
+                const float wy0 = 1.0f - fy;
+                const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
+                irradiance.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
+                irradiance.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
+                irradiance.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00 * t00.z)));
+            }
+            // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) ----------------------------------------
+            const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
+            F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
+            const float hr = rsq(dot(Hv, Hv));
+            const float NdotH = sat(dot(N, Hv) * hr);
+            const float VdotH = dot(V, Hv) * hr; // = (1 + V.L)/|V + L| in [0,1]: saturate is the identity up to rounding
+            const float alpha = roughness * roughness;
+            const float alpha2 = alpha * alpha;
+            const float denom = fmaf(NdotH * NdotH, alpha2 - 1.0f, 1.0f);
+            const float D = alpha2 * rcp(fmaxf(3.14159265f * denom * denom, 1e-4f));
+            float k = roughness + 1.0f;
+            k = (k * k) * 0.125f;
+            const float omk = 1.0f - k;
+            // G / max(4 NdotL NdotV, 1e-4) * D, one reciprocal for the three denominators
+            const float gv = fmaf(NdotV, omk, k), gl = fmaf(NdotL, omk, k);
+            float scs = (ablate & 4u) ? 0.5f : (D * NdotV * NdotL) * rcp(gv * gl * fmaxf(4.0f * NdotL * NdotV, 1e-4f));
+            const float om = 1.0f - VdotH;
+            const float om2 = om * om;
+            float p5 = (ablate & 4u) ? 0.5f : om2 * om2 * om;
+            float kdm = 1.0f - metallic;
+            // the math above is wanted BEFORE the first wait on a gather, not sunk behind it
+            asm volatile("" : "+v"(scs), "+v"(p5), "+v"(kdm), "+v"(ba), "+v"(bb), "+v"(irradiance.x), "+v"(irradiance.y), "+v"(irradiance.z));
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- shadow filter (its taps were issued last: their wait covers every gather) -------------------------------------
+            float shadow = 1.0f;
+            if (wave_lit && (ablate & 1u)) shadow = sa.x + sb.y + sc3.z;
+            else if (wave_lit) {
+                // PCF = 1 - 0.25 sum w (cmp > t) with separable weights (1-f, 1, f); then lerp(1, pcf, strength)
+                const float cb = cmp * 0x1p126f;
+                const float wx0 = 1.0f - sfx, wy0 = 1.0f - sfy;
+                const float r0 = fmaf(gt_step(cb, sa.z, negBig), sfx, fmaf(gt_step(cb, sa.x, negBig), wx0, gt_step(cb, sa.y, negBig)));
+                const float r1 = fmaf(gt_step(cb, sb.z, negBig), sfx, fmaf(gt_step(cb, sb.x, negBig), wx0, gt_step(cb, sb.y, negBig)));
+                const float r2 = fmaf(gt_step(cb, sc3.z, negBig), sfx, fmaf(gt_step(cb, sc3.x, negBig), wx0, gt_step(cb, sc3.y, negBig)));
+                shadow = fmaf(fmaf(sfy, r2, fmaf(wy0, r0, r1)), q->shadowNegQuarterStrength, 1.0f);
+                if (__builtin_expect(__any(!fast), 0)) { // some pixel's footprint touches the border (or lies outside the map)
+                    const bool lit = xa >= -0.5f && ya >= -0.5f && xa <= q->shadowXmax && ya <= q->shadowYmax;
+                    if (!fast) {
+                        const float xa0 = floorf(xa), ya0 = floorf(ya);
+                        const float s = shadow_pcf_border_inline(q->shadow, q->shadowWi, q->shadowHi, (int)xa0, (int)ya0, sfx, sfy, cmp);
+                        shadow = mix(1.0f, s, q->shadowStrength);
+                    }
+                    if (!lit) shadow = 1.0f;
+                }
+            }
+            need(p0a, p0b, p1a, p1b);
+            if (!IRR_LDS) need(pia, pib, pia, pib);
+            __builtin_amdgcn_sched_barrier(0);
+            // hipcc has no load of its own in flight here: the DMA for the tile two steps ahead goes into the buffer just read.
+            // The vmcnt(0) retires every older vector-memory operation of the wave, in particular the DMA issued at the previous
+            // iteration's prefetch point: the tile the NEXT iteration reads is in LDS from here on.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more2) tile_prefetch<MODE>(kp, q->W, q->rows, src, lane, tx2, ty2, bufBase + parity * kTileBytes);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- filter, combine ---------------------------------------------------------------------------------------------------
+            const float sh_l = shadow * NdotL;
+            F3 prefiltered = f3(fx0, fy1, fl);
+            if (!(ablate & 2u)) {
+                CubeTaps t;
+                t.r0 = uint4u{p0a.x, p0a.y, p0a.z, p0a.w}; t.r1 = uint4u{p0b.x, p0b.y, p0b.z, p0b.w}; t.fx = fx0; t.fy = fy0;
+                cube_taps_filter<false>(prefiltered, t, 1.0f - fl);
+                t.r0 = uint4u{p1a.x, p1a.y, p1a.z, p1a.w}; t.r1 = uint4u{p1b.x, p1b.y, p1b.z, p1b.w}; t.fx = fx1; t.fy = fy1;
+                cube_taps_filter<true>(prefiltered, t, fl);
+                if (!IRR_LDS) {
+                    t.r0 = uint4u{pia.x, pia.y, pia.z, pia.w}; t.r1 = uint4u{pib.x, pib.y, pib.z, pib.w}; t.fx = fxi; t.fy = fyi;
+                    cube_taps_filter<false>(irradiance, t, 1.0f); // irrFrac == 0 in this kernel
+                }
+            }
+            F3 color;
+#define UR_CHANNEL(ch, i)                                                                                     \
+    {                                                                                                         \
+        const float A = kdm * albedo.ch;                     /* (1 - metallic) * albedo: diffuse weight, also irradiance's */ \
+        const float F = fmaf(1.0f - F0.ch, p5, F0.ch);                                                        \
+        const float direct = fmaf(F, scs - A, A);            /* (1-F) A + F sc */                            \
+        const float ambient = fmaf(irradiance.ch, A, prefiltered.ch * fmaf(F0.ch, ba, bb));                   \
+        color.ch = fmaf(direct, q->lightRGB[i] * sh_l, ambient);                                              \
+    }
+            UR_CHANNEL(x, 0)
+            UR_CHANNEL(y, 1)
+            UR_CHANNEL(z, 2)
+#undef UR_CHANNEL
+            if (!sky) {
+                out = f3(h2f_lo(gd.x) + color.x, h2f_hi(gd.x) + color.y, h2f_lo(gd.y) + color.z);
+                outw = h2f_hi(gd.y) + 1.0f;
+            }
         } else {
-            nxt = fetch_pixel<MODE, TW>(p, pf, tilesX, lane, wave);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more2) tile_prefetch<MODE>(kp, q->W, q->rows, src, lane, tx2, ty2, bufBase + parity * kTileBytes);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (cur.valid) {
+        if (ty * 4u + row < q->rows) { // false only in the rows a partial bottom tile hangs over the band
             half4_t o;
-            o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z;
-            o.w = sky ? (_Float16)1.0f : (_Float16)((float)cur.d.w + 1.0f);
-            st<half4_t>(p.hdr, cur.i * 8u, o);
+            o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z; o.w = (_Float16)outw;
+            const uint32_t i = (ty * 4u + row) * q->W + tx * 16u + col;
+            st<half4_t>(q->hdr, i * 8u, o);
         }
-        if (!more) break;
-        cur = nxt;
-        tile = next;
+        tile += G;
+        if (tile >= q->numTiles) break;
+        tx = tx1; ty = ty1; tx1 = tx2; ty1 = ty2;
+        parity ^= 1u;
     }
 }
 
@@ -549,40 +963,51 @@ int env_int(const char* name, int dflt)
     return e ? std::atoi(e) : dflt;
 }
 
-template <int MODE, bool SHADOWS, int TW>
-void launch_tile_shape(ur_ctx* ctx, const LightingParams& p)
-{
-    const uint32_t tilesX = (p.W + 4 * TW - 1) / (4 * TW), tilesY = (p.rows + (64 / TW) - 1) / (64 / TW);
-    if constexpr (MODE != ur::UR_MODE_SKY) {
-        static const int bpc = env_int("UR_LIGHTING_PERSISTENT", 0); // 0 = one workgroup per tile; N = N persistent workgroups per CU
-        const uint32_t numTiles = tilesX * tilesY;
-        if (bpc > 0 && numTiles > (uint32_t)(ctx->cu_count * bpc)) {
-            if (bpc >= 6) hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW, 6>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
-            else if (bpc == 5) hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW, 5>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
-            else hipLaunchKernelGGL((lighting_kernel_persistent<MODE, SHADOWS, TW, 4>), dim3(ctx->cu_count * bpc), dim3(256), 0, ctx->stream, p, tilesX, numTiles);
-            return;
-        }
-    }
-    // register budget: waves/SIMD the kernel is compiled for (6 -> 80 VGPRs, 4 -> no cap)
-    static const int waves = env_int("UR_LIGHTING_WAVES", 6); // measured T ~ 65 us + 247 us / waves-per-SIMD: 6 waves (80 VGPRs) is the most that does not spill
-    static const int ldspad = env_int("UR_LIGHTING_LDSPAD", 0); // diagnostic: unused dynamic LDS to throttle workgroups per CU
-    if (waves >= 8) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 8>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
-    else if (waves == 7) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 7>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
-    else if (waves == 6) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
-    else hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 4>), dim3(tilesX, tilesY), dim3(256), ldspad, ctx->stream, p);
-}
-
+// Per-tile kernel (one 64x4-pixel workgroup per tile): partial tiles, sky-only launches and configurations the streaming
+// kernel does not cover.
 template <int MODE, bool SHADOWS>
 void launch_tiled(ur_ctx* ctx, const LightingParams& p)
 {
-    // pixels per wave = TW x (64/TW). 16 x 4: 128-byte G-buffer row segments and compact gather footprints.
-    static const int tw = env_int("UR_LIGHTING_TW", 16);
-    switch (tw) {
-    case 8: launch_tile_shape<MODE, SHADOWS, 8>(ctx, p); break;
-    case 32: launch_tile_shape<MODE, SHADOWS, 32>(ctx, p); break;
-    case 64: launch_tile_shape<MODE, SHADOWS, 64>(ctx, p); break;
-    default: launch_tile_shape<MODE, SHADOWS, 16>(ctx, p); break;
+    constexpr int TW = 16; // pixels per wave = 16 x 4: 128-byte G-buffer row segments and compact gather footprints
+    const uint32_t tilesX = (p.W + 4 * TW - 1) / (4 * TW), tilesY = (p.rows + (64 / TW) - 1) / (64 / TW);
+    // register budget: waves/SIMD the kernel is compiled for (6 -> 80 VGPRs, the most that does not spill; 4 -> no cap)
+    static const int waves = env_int("UR_LIGHTING_WAVES", 6);
+    if (waves >= 6) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 4>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
+}
+
+template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
+int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk is filled in here */)
+{
+    constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
+    auto kern = lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB>;
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        UR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
     }
+    StreamHot& h = p.hot;
+    h.tilesX = p.W / 16u;
+    h.numTiles = h.tilesX * ((p.rows + 3u) / 4u);
+    const uint32_t groups = std::min<uint32_t>((uint32_t)ctx->cu_count * (WPB == 10 ? 2u : 1u), (h.numTiles + WPB - 1) / WPB);
+    const uint32_t G = groups * WPB; // waves in the grid = tile stride of one wave
+    h.stepX = G % h.tilesX;
+    h.stepY = G / h.tilesX;
+    static const int ablate = env_int("UR_LIGHTING_ABLATE", 0);
+    h.ablate = (uint32_t)ablate;
+    hipLaunchKernelGGL(kern, dim3(groups), dim3(64 * WPB), lds, ctx->stream, p);
+    return UR_OK;
+}
+
+// One persistent workgroup per CU; waves per SIMD = WPB / 4 (VGPR budget 512 / that).
+template <int MODE, bool SHADOWS, bool IRR_LDS>
+int launch_stream(ur_ctx* ctx, const LightingParams& p)
+{
+    static const int wpb = env_int("UR_LIGHTING_WPB", 16);
+    if (wpb >= 16) return launch_stream_wpb<MODE, SHADOWS, IRR_LDS, 16>(ctx, p);
+    if (wpb == 10) return launch_stream_wpb<MODE, SHADOWS, IRR_LDS, 10>(ctx, p);
+    if (wpb <= 8) return launch_stream_wpb<MODE, SHADOWS, IRR_LDS, 8>(ctx, p);
+    return launch_stream_wpb<MODE, SHADOWS, IRR_LDS, 12>(ctx, p);
 }
 
 } // namespace
@@ -693,14 +1118,73 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         set_error("band of %u x %u pixels exceeds the 2^29-pixel limit of one launch", w, rows);
         return UR_EUNSUPPORTED;
     }
-    switch (mode) {
-    case UR_MODE_LIGHTING:
-        if (shadows) launch_tiled<UR_MODE_LIGHTING, true>(ctx, p); else launch_tiled<UR_MODE_LIGHTING, false>(ctx, p);
-        break;
-    case UR_MODE_SKY: launch_tiled<UR_MODE_SKY, false>(ctx, p); break;
-    default:
-        if (shadows) launch_tiled<UR_MODE_FUSED, true>(ctx, p); else launch_tiled<UR_MODE_FUSED, false>(ctx, p);
-        break;
+    // ---- streaming kernel when the band is a whole number of 16-pixel tile columns; the per-tile kernel otherwise -----------
+    static const int use_stream = env_int("UR_LIGHTING_STREAM", 1);
+    bool streamed = false;
+    if (use_stream && mode != UR_MODE_SKY && w % 16u == 0 && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
+        bool ok = true;
+        StreamHot& h = p.hot;
+        if (shadows) {
+            // orthographic light (BuildDirectionalLightViewProjection, RendererUtils.cpp:1117-1137): clip.w == 1, so
+            // su * W - 0.5, sv * H - 0.5 and depth - bias are affine in viewZ * (ra, rb, 1)
+            ok = p.SQ[3] == 0.0f && p.SQ[7] == 0.0f && p.SQ[11] == 0.0f && p.ST[3] == 1.0f;
+            const double hw = 0.5 * p.shadowW, hh = 0.5 * p.shadowH;
+            for (int k = 0; k < 3; ++k) {
+                h.shX[k] = (float)(p.SQ[4 * k + 0] * hw);
+                h.shY[k] = (float)(p.SQ[4 * k + 1] * -hh);
+                h.shZ[k] = p.SQ[4 * k + 2];
+            }
+            h.shX[3] = (float)(p.ST[0] * hw + hw - 0.5);
+            h.shY[3] = (float)(p.ST[1] * -hh + hh - 0.5);
+            h.shZ[3] = p.ST[2] - p.shadowBias;
+            h.shadowXmax = p.shadowW - 0.5f;
+            h.shadowYmax = p.shadowH - 0.5f;
+            h.shadowWi = p.shadowWi; h.shadowHi = p.shadowHi;
+            h.shadowWm3 = (float)(p.shadowWi - 3); h.shadowHm3 = (float)(p.shadowHi - 3); h.shadowWf = (float)p.shadowWi;
+            h.shadowRowBytes = (uint32_t)p.shadowWi * 4u;
+            h.shadowStrength = p.shadowStrength;
+            h.shadowNegQuarterStrength = -0.25f * p.shadowStrength;
+            h.shadow = p.shadow;
+            ok = ok && (uint64_t)p.shadowWi * (uint64_t)p.shadowHi < (1ull << 24); // texel indices are computed in fp32 (exact below 2^24)
+        }
+        if (ok) {
+            h.W = p.W; h.rows = p.rows; h.row0 = p.row0;
+            h.invW2 = p.invW2; h.invH2 = p.invH2;
+            h.invP11 = p.invP11; h.nInvP22 = -p.invP22;
+            h.skyInvP11 = p.skyInvP11; h.nSkyInvP22 = -p.skyInvP22;
+            h.skyNearOverR2 = p.skyNearOverR * p.skyNearOverR;
+            h.maxMip = p.maxMip;
+            h.envMaxLevel = (float)(p.envMips - 1u);
+            const uint32_t iE = p.irrN0 + 2u;
+            h.irrN0 = p.irrN0; h.irrNf = (float)p.irrN0; h.irrEf = (float)iE; h.irrEEf = (float)(iE * iE);
+            h.irrOfff = (float)p.irrOffset0; h.irrRowBytes = iE * 8u;
+            h.env = p.env; h.hdr = p.hdr;
+            for (int k = 0; k < 9; ++k) h.R[k] = p.R[k];
+            for (int k = 0; k < 3; ++k) { h.L[k] = p.L[k]; h.lightRGB[k] = p.lightRGB[k]; }
+            streamed = true;
+            const LightingParams& q = p;
+            const bool irr_lds = p.irrN0 <= 2u;
+            int rc;
+            if (mode == UR_MODE_LIGHTING) {
+                if (shadows) rc = irr_lds ? launch_stream<UR_MODE_LIGHTING, true, true>(ctx, q) : launch_stream<UR_MODE_LIGHTING, true, false>(ctx, q);
+                else rc = irr_lds ? launch_stream<UR_MODE_LIGHTING, false, true>(ctx, q) : launch_stream<UR_MODE_LIGHTING, false, false>(ctx, q);
+            } else {
+                if (shadows) rc = irr_lds ? launch_stream<UR_MODE_FUSED, true, true>(ctx, q) : launch_stream<UR_MODE_FUSED, true, false>(ctx, q);
+                else rc = irr_lds ? launch_stream<UR_MODE_FUSED, false, true>(ctx, q) : launch_stream<UR_MODE_FUSED, false, false>(ctx, q);
+            }
+            if (rc != UR_OK) return rc;
+        }
+    }
+    if (!streamed) {
+        switch (mode) {
+        case UR_MODE_LIGHTING:
+            if (shadows) launch_tiled<UR_MODE_LIGHTING, true>(ctx, p); else launch_tiled<UR_MODE_LIGHTING, false>(ctx, p);
+            break;
+        case UR_MODE_SKY: launch_tiled<UR_MODE_SKY, false>(ctx, p); break;
+        default:
+            if (shadows) launch_tiled<UR_MODE_FUSED, true>(ctx, p); else launch_tiled<UR_MODE_FUSED, false>(ctx, p);
+            break;
+        }
     }
     UR_HIP_TRY(hipGetLastError());
     return UR_OK;
