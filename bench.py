@@ -229,7 +229,7 @@ def main():
             "async_compute": not args.no_async, "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
         },
         "roofline": {
-            "kernel": "lighting_kernel<FUSED>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": "lighting_stream_kernel<FUSED>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float(light_ms.min()) * 1e3,
             "shade_only_mpixels_per_s": g.depth.size * N / light_avg_s / 1e6,

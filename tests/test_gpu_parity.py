@@ -237,6 +237,62 @@ def test_lighting_without_shadows(hotpath, oracle):
     assert nbad == 0, (nbad, worst)
 
 
+@pytest.mark.parametrize("w,h", [(16, 1), (16, 5), (32, 3), (48, 7), (64, 4), (272, 33), (24, 9), (130, 3), (1, 1)])
+@pytest.mark.parametrize("mode", ["scene", "iid"])
+def test_lighting_tile_geometry(hotpath, oracle, w, h, mode):
+    """The streaming lighting kernel walks 16x4-pixel tiles (partial bottom tiles hang over the band); widths that are
+    not a multiple of 16 take the per-tile kernel. Every shape agrees with the oracle, fused and lighting-only."""
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=100 + w + h, mode=mode)
+    tables = _device_tables(hotpath, shadow, env, lut)
+    ref_l, fragile = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 32, 6, lut, g.hdr, w, h, want_fragile=True)
+    ref_s = oracle.sky_atmosphere(fc.sky, g.depth, ref_l, w, h)
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+    d1, d2 = to_device(g.hdr), to_device(g.hdr)
+    hotpath.deferred_lighting(fc.scene, dA, dB, dC, tables, d1, w, h)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, d2, w, h)
+    torch.cuda.synchronize()
+    nbad, worst, _ = hdr_mismatch(d1.cpu().numpy().view(np.uint16), ref_l, exclude=fragile)
+    assert nbad == 0, f"lighting {w}x{h}: {nbad} beyond tolerance (worst {worst})"
+    nbad, worst, _ = hdr_mismatch(d2.cpu().numpy().view(np.uint16), ref_s, exclude=fragile)
+    assert nbad == 0, f"fused {w}x{h}: {nbad} beyond tolerance (worst {worst})"
+
+
+def test_lighting_band_offsets(hotpath, oracle):
+    """A band that starts in the middle of the frame and is not a multiple of the tile height (a 1-of-8 shard of 1080p)."""
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    w, h, r0, rows = 320, 270, 135, 34
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=9, mode="scene")
+    tables = _device_tables(hotpath, shadow, env, lut)
+    sl = slice(r0, r0 + rows)
+    ref_l, fragile = oracle.deferred_lighting(fc.scene, g.A[sl], g.B[sl], g.C[sl], shadow, env, 32, 6, lut, g.hdr[sl], w, h, r0, rows, want_fragile=True)
+    ref = oracle.sky_atmosphere(fc.sky, g.depth[sl], ref_l, w, h, r0, rows)
+    out = to_device(g.hdr[sl])
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A[sl]), to_device(g.B[sl]), to_device(g.C[sl]), to_device(g.depth[sl]), tables, out, w, h, r0, rows)
+    torch.cuda.synchronize()
+    nbad, worst, _ = hdr_mismatch(out.cpu().numpy().view(np.uint16), ref, exclude=fragile)
+    assert nbad == 0, (nbad, worst)
+
+
+def test_lighting_shadow_border_and_outside(hotpath, oracle):
+    """A small shadow map whose frustum does not cover the view: PCF footprints on the border (opaque white) and pixels
+    outside the map (shadow = 1) take the slow path of both kernels."""
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    w, h = 192, 108
+    fc, g, shadow, env, lut = _lighting_inputs("duck", w, h, seed=17, mode="scene", shadow_size=8)
+    tables = _device_tables(hotpath, shadow, env, lut)
+    ref_l, fragile = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 32, 6, lut, g.hdr, w, h, want_fragile=True)
+    d = to_device(g.hdr)
+    hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, d, w, h)
+    torch.cuda.synchronize()
+    nbad, worst, _ = hdr_mismatch(d.cpu().numpy().view(np.uint16), ref_l, exclude=fragile)
+    assert nbad == 0, (nbad, worst)
+    assert fragile.mean() < 0.05
+
+
 def test_row_bands_equal_whole_frame(hotpath):
     """Screen-tile sharding: shading 4 bands separately gives the whole-frame result bit for bit."""
     from unclerenderer_amd.hotpath import to_device

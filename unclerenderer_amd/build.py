@@ -30,7 +30,9 @@ SOURCES = [
     ("ur_api.hip", []),
     ("hzb.hip", EXACT),
     ("cull.hip", EXACT),
-    ("lighting.hip", ["-fno-slp-vectorize"]),  # packed fp32 VALU ops are not faster on gfx950 and cost v_mov traffic
+    # packed fp32 VALU ops are not faster on gfx950 and cost v_mov traffic; the atomic optimizer would turn the one-lane LDS
+    # work-counter claim into a scan + broadcast with an immediate wait
+    ("lighting.hip", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]),
     ("tonemap.hip", []),
     ("taa.hip", EXACT),
     ("scene.cpp", ["-x", "hip"] + EXACT),
@@ -62,6 +64,8 @@ def _stale(target: Path, srcs: list[Path]) -> bool:
 
 def _compile(job) -> Path:
     src, flags, force = job
+    if os.environ.get("UR_BUILD_STAMPS") == "1" and src == "lighting.hip":
+        flags = flags + ["-DUR_STAMPS"]  # diagnostic build: in-kernel cycle stamps (never the shipped configuration)
     srcp = CSRC / src
     obj = OUT / (src.replace("/", "_") + ".o")
     if force or _stale(obj, [srcp] + _deps()):

@@ -29,11 +29,10 @@ namespace {
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-// The launch-uniform values one iteration of the streaming kernel reads, contiguous so that they arrive in a few wide
-// scalar loads at the top of the iteration.
+// The launch-uniform values of the streaming kernel's loop. The hot ones stay in SGPRs across the loop; cold paths (sky
+// constants, shadow slow path, partial tiles) re-read theirs from the kernarg segment when they run (fresh_params()).
 struct StreamHot {
-    uint32_t tilesX, numTiles, stepX, stepY, W, rows, row0, irrN0, irrRowBytes;
-    uint32_t ablate; // diagnostic (UR_LIGHTING_ABLATE): bit 0 no PCF math, 1 no cube filter, 2 no BRDF math, 3 no global gathers, 4 no LDS lookups
+    uint32_t tilesX, numTiles, tilesXMagic, W, rows, row0, irrN0, irrRowBytes; // tilesXMagic: tile / tilesX = (tile * magic) >> 32
     float invW2, invH2, invP11, nInvP22;      // ray: ra = ndc.x * invP11, rb = ndc.y * nInvP22 (= -1/P22)
     float skyInvP11, nSkyInvP22, skyNearOverR2, maxMip;
     float envMaxLevel, irrNf, irrEf, irrEEf, irrOfff; // irradiance mip: N, N+2, (N+2)^2, texel offset — as floats (exact)
@@ -44,8 +43,13 @@ struct StreamHot {
     const void* env;
     const float* shadow;
     void* hdr;
-    float R[9], L[3], lightRGB[3];
-    float shX[4], shY[4], shZ[4];     // su * W - 0.5 = viewZ * (ra * shX[0] + rb * shX[1] + shX[2]) + shX[3], ...; shZ: depth - bias
+    float skyDepthMax;   // no sphere depth of the frame exceeds it
+    // read once per wave into VGPRs
+    float R[9];          // (float3x3)ViewInverse, row-major
+    float Lw[3];         // light direction, world space
+    float WA[3], WB[3], WC[3]; // world-space camera ray through the pixel = ndc.x * WA + ndc.y * WB + WC
+    float lightRGB[3];
+    float shA[3], shB[3], shC[3], shT[3]; // (su * W - 0.5, sv * H - 0.5, depth - bias)[k] = viewZ * (ndc.x * shA[k] + ndc.y * shB[k] + shC[k]) + shT[k]
 };
 
 struct LightingParams {
@@ -77,6 +81,7 @@ struct LightingParams {
     float skyMie[3];     // LightColor * mieDensity * 0.8 * (1-g^2)/(4 pi)
     float sunAttenuation;
     StreamHot hot;       // streaming kernel: everything one loop iteration reads
+    unsigned long long* stamps; // diagnostic builds (-DUR_STAMPS): per-wave cycle sums of the loop segments
     // buffers
     const half4_t* A;
     const half4_t* B;
@@ -518,9 +523,10 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
 // =====================================================================================================================
 constexpr uint32_t kLutW = 128, kLutH = 32, kLutE = kLutW + 2;    // streaming kernel: LUT dimensions are compile-time
 constexpr uint32_t kLdsSrgb = 0;                                    // 256 floats
+constexpr uint32_t kLdsWork = 1024 + 17 * 32 + 6 * 16 * 16;         // the workgroup's tile counter (one dword, 16 reserved)
 constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
 constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // up to 6 * 4 * 4 float4 (irradiance mip, N <= 2)
-constexpr uint32_t kLdsLut = kLdsIrr + 6 * 16 * 16;                 // (kLutW + 2) x (kLutH + 2) float2
+constexpr uint32_t kLdsLut = kLdsIrr + 6 * 16 * 16 + 16;            // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
 static_assert(kLdsTiles % 16 == 0, "tile buffers are 16-byte aligned");
@@ -589,20 +595,6 @@ __device__ __forceinline__ void tile_prefetch(P p, uint32_t W, uint32_t rows, co
     else tile_dma(tile_src<MODE>(p, lane, rowsLeft - 1u), origin, lds_dst);
 }
 
-// One iteration's copy of the hot block (a handful of wide scalar loads).
-struct HotView {
-    StreamHot h;
-    __device__ __forceinline__ explicit HotView(KParams kp)
-    {
-        constexpr uint32_t n = sizeof(StreamHot) / 4u;
-        const __attribute__((address_space(4))) uint32_t* src = reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(&kp->hot);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&h);
-#pragma unroll
-        for (uint32_t i = 0; i < n; ++i) dst[i] = src[i];
-    }
-    __device__ __forceinline__ const StreamHot* operator->() const { return &h; }
-};
-
 struct __attribute__((aligned(16))) float4a { float x, y, z, w; };
 
 // A launch-uniform value pinned in a VGPR (a VOP3 instruction reads at most one SGPR: the second uniform operand of an FMA
@@ -644,6 +636,18 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 }
 
 // WPB waves per workgroup; WPB = 10 runs two workgroups per CU (5 waves/SIMD, 96 VGPRs), the others one.
+#ifdef UR_STAMPS
+// In-kernel stamps (diagnostic build only; cdna_hip_programming.md section 7): one statement = s_memtime + its own wait.
+#define UR_STAMP(var)                                                                        \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define UR_STAMP(var) do { } while (0)
+#endif
+
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_kernel(LightingParams p)
 {
@@ -653,25 +657,36 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     MipEntry* mipT = reinterpret_cast<MipEntry*>(smem + kLdsMip);
     float4a* irrT = reinterpret_cast<float4a*>(smem + kLdsIrr);
     float2* lut = reinterpret_cast<float2*>(smem + kLdsLut);
+    uint32_t* work = reinterpret_cast<uint32_t*>(smem + kLdsWork);
 
-    // ---- stage the tables (once per workgroup) ----------------------------------------------------------------------
-    for (uint32_t i = threadIdx.x; i < 256u; i += 64 * WPB) srgb[i] = p.srgb[i];
-    if (threadIdx.x < 17u) {
-        const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
-        const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
-        mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * E), (float)p.envMipOffset[m], E * 8u, 0u, 0u, 0u};
-    }
-    for (uint32_t i = threadIdx.x; i < kLutE * (kLutH + 2u); i += 64 * WPB) {
-        const uint32_t by = i / kLutE, bx = i - by * kLutE;
-        const uint32_t sx = min(max(bx, 1u), kLutW) - 1u, sy = min(max(by, 1u), kLutH) - 1u; // border = clamp addressing
-        const uint32_t t = p.lut[sy * kLutW + sx];
-        lut[i] = float2{(float)(t & 0xFFFFu) / 65535.0f, (float)(t >> 16) / 65535.0f};     // the oracle's texel values
-    }
-    if (IRR_LDS) {
-        const uint32_t E = p.irrN0 + 2u, n = 6u * E * E;
-        for (uint32_t i = threadIdx.x; i < n; i += 64 * WPB) {
-            const half4_t h = p.env[p.irrOffset0 + i];
-            irrT[i] = float4a{(float)h.x, (float)h.y, (float)h.z, 0.0f};
+    // ---- stage the tables (once per workgroup): every load is issued before the first result is converted, so the
+    //      workgroup pays one memory latency, not one per loop trip -----------------------------------------------------
+    {
+        constexpr uint32_t T = 64 * WPB, kLutN = kLutE * (kLutH + 2u), kLutTrips = (kLutN + T - 1) / T;
+        uint32_t lt[kLutTrips];
+#pragma unroll
+        for (uint32_t k = 0; k < kLutTrips; ++k) {
+            const uint32_t i = min(threadIdx.x + k * T, kLutN - 1u);
+            const uint32_t by = i / kLutE, bx = i - by * kLutE;
+            const uint32_t sx = min(max(bx, 1u), kLutW) - 1u, sy = min(max(by, 1u), kLutH) - 1u; // border = clamp addressing
+            lt[k] = p.lut[sy * kLutW + sx];
+        }
+        const float sv = threadIdx.x < 256u ? p.srgb[threadIdx.x] : 0.0f;
+        half4_t ih = {};
+        const uint32_t irrE = p.irrN0 + 2u, irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
+        if (threadIdx.x < irrCount) ih = p.env[p.irrOffset0 + threadIdx.x];
+        if (threadIdx.x == 0) *work = 2u * WPB;
+        if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
+        if (threadIdx.x < irrCount) irrT[threadIdx.x] = float4a{(float)ih.x, (float)ih.y, (float)ih.z, 0.0f};
+        if (threadIdx.x < 17u) {
+            const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
+            const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
+            mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * E), (float)p.envMipOffset[m], E * 8u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kLutTrips; ++k) {
+            const uint32_t i = threadIdx.x + k * T;
+            if (i < kLutN) lut[i] = float2{(float)(lt[k] & 0xFFFFu) / 65535.0f, (float)(lt[k] >> 16) / 65535.0f}; // the oracle's texel values
         }
     }
     __syncthreads();
@@ -679,10 +694,16 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform by construction: keeps the tile walk on the scalar ALU
     const uint32_t G = gridDim.x * WPB;
-    uint32_t tile = blockIdx.x * WPB + wave;
-    if (tile >= p.hot.numTiles) return; // no barrier below
-    // tile -> (tx, ty) once by division, then incrementally (scalar ALU only)
+    // Tile schedule: block-cyclic over the workgroups (round r gives workgroup b the WPB consecutive tiles starting at
+    // (r * groups + b) * WPB), dynamic inside the workgroup: a wave takes its next tile from a counter in LDS. The SIMD's
+    // oldest-first arbitration lets some waves of a workgroup run up to twice as fast as others (measured with in-kernel
+    // stamps); with a static split the slow ones set the kernel's duration, with the counter all of them finish together.
+    // Claims c = wave and c = WPB + wave are static (the two tiles of the prologue).
+    const uint32_t chunkStride = gridDim.x * WPB, base = blockIdx.x * WPB;
+    uint32_t tile = base + wave, tile1 = chunkStride + base + wave; // c -> (c / WPB) * chunkStride + base + c % WPB
+    const bool have0 = tile < p.hot.numTiles; // (a grid larger than the band: some waves have no tile at all)
     uint32_t ty = tile / p.hot.tilesX, tx = tile - ty * p.hot.tilesX;
+    uint32_t ty1 = tile1 / p.hot.tilesX, tx1 = tile1 - ty1 * p.hot.tilesX;
     const uint32_t col = lane & 15u, row = lane >> 4;
     const TileSrc src = tile_src<MODE>(&p, lane, 3u);
     const uint32_t bufBase = __builtin_amdgcn_readfirstlane(lds_address(smem + kLdsTiles + wave * (2u * kTileBytes)));
@@ -691,62 +712,91 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     // SECOND scalar operand of an FMA
     const float ndcxL = fmaf((float)col, p.invW2, 0.5f * p.invW2 - 1.0f);
     const float rowh = (float)row + 0.5f; // ndc.y = (py + 0.5) * 2/H - 1 with py = row0 + 4 ty + row summed exactly: a band and the whole frame agree bit for bit
-    const float shX2 = vreg(p.hot.shX[2]), shY2 = vreg(p.hot.shY[2]), shZ2 = vreg(p.hot.shZ[2]);
     const float negBig = vreg(-0x1p126f);
+    // Launch constants of the FMA-dense parts as VGPR operands: two neighbouring VALU instructions that both read an SGPR
+    // cannot share an issue slot (tools/microbench/valu_rate4.hip), and a VOP3 reads one SGPR at most.
+    float R[9], WC[3], shC[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = vreg(p.hot.R[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); }
 
-    // ---- prologue: tiles t and t+G in flight, wait for both --------------------------------------------------------------
-    tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
-    uint32_t tx1 = tx + p.hot.stepX, ty1 = ty + p.hot.stepY;
-    if (tx1 >= p.hot.tilesX) { tx1 -= p.hot.tilesX; ty1 += 1u; }
-    if (tile + G < p.hot.numTiles) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
+    // ---- prologue: the wave's two static tiles in flight, wait for both --------------------------------------------------
+    if (have0) {
+        tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
+        if (tile1 < p.hot.numTiles) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     uint32_t parity = 0;
-    for (;;) {
-        // every launch-uniform value of the iteration in a few wide scalar loads
-        const KParams kp = fresh_params();
-        HotView q(kp);
-        // (tx2, ty2) = the tile two steps ahead (prefetched in this iteration)
-        uint32_t tx2 = tx1 + q->stepX, ty2 = ty1 + q->stepY;
-        if (tx2 >= q->tilesX) { tx2 -= q->tilesX; ty2 += 1u; }
-        const bool more2 = tile + 2u * G < q->numTiles; // uniform
+// (macro: the statement appears in the shading path and in the all-sky path)
+#define UR_PREFETCH_POINT()                                                                                              \
+    do {                                                                                                                 \
+        if (more1) {                                                                                                     \
+            const uint32_t c = __builtin_amdgcn_readfirstlane(claim);                                                    \
+            tile2 = (c / WPB) * chunkStride + base + c % WPB;                                                            \
+            more2 = tile2 < p.hot.numTiles;                                                                                 \
+            if (more2) {                                                                                                 \
+                ty2 = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)tile2 * p.hot.tilesXMagic) >> 32));              \
+                tx2 = tile2 - ty2 * p.hot.tilesX;                                                                           \
+                tile_prefetch<MODE>(kp, p.hot.W, p.hot.rows, src, lane, tx2, ty2, bufBase + parity * kTileBytes);              \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
+#ifdef UR_STAMPS
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0, iters = 0;
+#endif
+    while (have0) {
+        UR_STAMP(tA);
+        const KParams kp = fresh_params(); // cold paths re-read what they need (sky constants, shadow slow path, partial tiles)
+        // the tile two steps ahead: claimed here (LDS atomic, long back when the prefetch point needs it)
+        uint32_t tile2 = 0xFFFFFFFFu, tx2 = 0, ty2 = 0;
+        bool more2 = false;
+        const bool more1 = tile1 < p.hot.numTiles; // uniform
+        uint32_t claim = 0;
+        if (more1 && lane == 0) claim = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned char* buf = myTiles + parity * kTileBytes;
         const uint2 ga = *reinterpret_cast<const uint2*>(buf + lane * 8u);          // (nx, ny), (nz, -viewZ)
         const uint2 gb = *reinterpret_cast<const uint2*>(buf + 512u + lane * 8u);   // (specular, metallic), (roughness, 1)
         const uint2 gd = *reinterpret_cast<const uint2*>(buf + 1024u + lane * 8u);  // HDR in
         const uint32_t gc = *reinterpret_cast<const uint32_t*>(buf + 1536u + lane * 4u);
-        const float ndcx = fmaf((float)(tx * 16u), q->invW2, ndcxL), ndcy = fmaf((float)(q->row0 + ty * 4u) + rowh, q->invH2, -1.0f);
+        const float ndcx = fmaf((float)(tx * 16u), p.hot.invW2, ndcxL), ndcy = fmaf((float)(p.hot.row0 + ty * 4u) + rowh, p.hot.invH2, -1.0f);
 
         bool sky = false;
         F3 out = f3(0.0f, 0.0f, 0.0f);
         if (MODE == ur::UR_MODE_FUSED) {
             const float depth = *reinterpret_cast<const float*>(buf + 1792u + lane * 4u);
-            const float vx = ndcx * q->skyInvP11, vy = ndcy * q->nSkyInvP22;
-            // sphere depth (Near/R) * |(vx, vy, 1)| >= depth, compared squared (depth is in [0,1]): no square root
-            sky = q->skyNearOverR2 * fmaf(vx, vx, fmaf(vy, vy, 1.0f)) >= depth * depth;
-            if (sky) out = sky_pixel(kp, vx, vy);
+            // no pixel of the frame has a sphere depth above skyDepthMax: a wave of nearer geometry skips the per-pixel test
+            if (__any(!(depth > p.hot.skyDepthMax))) {
+                const float vx = ndcx * p.hot.skyInvP11, vy = ndcy * p.hot.nSkyInvP22;
+                // sphere depth (Near/R) * |(vx, vy, 1)| >= depth, compared squared (depth is in [0,1]): no square root
+                sky = p.hot.skyNearOverR2 * fmaf(vx, vx, fmaf(vy, vy, 1.0f)) >= depth * depth;
+                if (sky) out = sky_pixel(kp, vx, vy);
+            }
         }
         float outw = 1.0f;
         if (__any(!sky)) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
-            const float ra = ndcx * q->invP11, rb = ndcy * q->nInvP22;
-            // ---- decode, view vectors ----------------------------------------------------------------------------------------
+            // ---- decode; every vector in WORLD space (the view matrix is rigid): the camera ray through the pixel is affine in
+            //      ndc, the normal is rotated once, and the reflection vector needs no rotation of its own ----------------------
             const float nx = h2f_lo(ga.x), ny = h2f_hi(ga.x), nz = h2f_lo(ga.y), wv = h2f_hi(ga.y);
             const float nr = rsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx))); // normalize(0) = NaN, as in the reference
-            const F3 N = f3(nx * nr, ny * nr, nz * nr);
+            const F3 N = rot(f3(nx * nr, ny * nr, nz * nr), R);
             const float viewZ = -wv;
             const float spec0 = h2f_lo(gb.x), metallic = h2f_hi(gb.x), roughness = h2f_lo(gb.y);
-            // V = normalize(-viewPos) = -sign(viewZ) (ra, rb, 1) / |(ra, rb, 1)|; sign(-viewZ) is the stored sign of A.w
-            const float vs = __builtin_copysignf(rsq(fmaf(ra, ra, fmaf(rb, rb, 1.0f))), wv);
-            const F3 V = f3(ra * vs, rb * vs, vs);
-            const F3 L = f3(q->L[0], q->L[1], q->L[2]);
+            const F3 Wd = f3(fmaf(ndcx, p.hot.WA[0], fmaf(ndcy, p.hot.WB[0], WC[0])), fmaf(ndcx, p.hot.WA[1], fmaf(ndcy, p.hot.WB[1], WC[1])),
+                             fmaf(ndcx, p.hot.WA[2], fmaf(ndcy, p.hot.WB[2], WC[2]))); // (ra, rb, 1) * ViewInverse3x3
+            // V = normalize(-viewPos) = -sign(viewZ) Wd / |Wd|; sign(-viewZ) is the stored sign of A.w
+            const float vs = __builtin_copysignf(rsq(dot(Wd, Wd)), wv);
+            const F3 V = f3(Wd.x * vs, Wd.y * vs, Wd.z * vs);
+            const F3 L = f3(p.hot.Lw[0], p.hot.Lw[1], p.hot.Lw[2]);
             const float NdotVraw = dot(N, V);
             const float NdotV = sat(NdotVraw);
             const float NdotL = sat(dot(N, L));
             // ---- global gathers: the two prefiltered mips (bordered cube, addresses in fp32: every integer multiply would hold
             //      the issue port), then the shadow block ------------------------------------------------------------------------
             const float t2 = 2.0f * NdotVraw;
-            const F3 Rw = rot(f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z)), q->R);
-            const float lvl = __builtin_amdgcn_fmed3f(roughness * q->maxMip, 0.0f, q->envMaxLevel);
+            const F3 Rw = f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z));
+            const float lvl = __builtin_amdgcn_fmed3f(roughness * p.hot.maxMip, 0.0f, p.hot.envMaxLevel);
             const float fl = __builtin_amdgcn_fractf(lvl);
             const MipEntry* me = mipT + (uint32_t)lvl;
             const float4a e0 = *reinterpret_cast<const float4a*>(me), e1 = *reinterpret_cast<const float4a*>(me + 1);
@@ -755,11 +805,9 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             const float invR = rcp(fabsf(__builtin_amdgcn_cubema(Rw.x, Rw.y, Rw.z)));
             const float uR = fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
             const float vR = fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
-            const void* env = q->env;
-            u32x4_t p0a = {0, 0, 0, 0}, p0b = p0a, p1a = p0a, p1b = p0a;
-            float fx0 = 0.0f, fy0 = 0.0f, fx1 = 0.0f, fy1 = 0.0f;
-            const uint32_t ablate = q->ablate;
-            if (!(ablate & 8u)) {
+            const void* env = p.hot.env;
+            u32x4_t p0a, p0b, p1a, p1b;
+            float fx0, fy0, fx1, fy1;
             {
                 const float x = fmaf(uR, e0.x, 0.5f), y = fmaf(vR, e0.x, 0.5f); // bordered coordinates in [0.5, N + 0.5]
                 const float i0 = floorf(x), j0 = floorf(y);
@@ -776,8 +824,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
                 p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB1));
             }
-            }
-            const F3 Nw = rot(N, q->R);
+            const F3 Nw = N;
             const float faceN = __builtin_amdgcn_cubeid(Nw.x, Nw.y, Nw.z);
             const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nw.x, Nw.y, Nw.z)));
             const float uN = fmaf(__builtin_amdgcn_cubesc(Nw.x, Nw.y, Nw.z), invN, 0.5f);
@@ -785,39 +832,40 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             u32x4_t pia = {0, 0, 0, 0}, pib = {0, 0, 0, 0};
             float fxi = 0.0f, fyi = 0.0f;
             if (!IRR_LDS) {
-                const float x = fmaf(uN, q->irrNf, 0.5f), y = fmaf(vN, q->irrNf, 0.5f);
+                const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
                 fxi = x - i0; fyi = y - j0;
-                const uint32_t o = (uint32_t)(fmaf(faceN, q->irrEEf, fmaf(j0, q->irrEf, i0)) + q->irrOfff) * 8u;
+                const uint32_t o = (uint32_t)(fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0)) + p.hot.irrOfff) * 8u;
                 pia = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
-                pib = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + q->irrRowBytes));
+                pib = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + p.hot.irrRowBytes));
             }
             // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF (direct = 0).
-            const bool wave_lit = SHADOWS && __any(NdotL > 0.0f) && !(ablate & 8u);
+            const bool wave_direct = __any(NdotL > 0.0f);
+            const bool wave_lit = SHADOWS && wave_direct;
             f32x3_t sa = {0, 0, 0}, sb = {0, 0, 0}, sc3 = {0, 0, 0};
             float xa = 0.0f, ya = 0.0f, cmp = 0.0f, sfx = 0.0f, sfy = 0.0f;
             bool fast = true;
             if (wave_lit) {
-                // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) are affine in viewZ * (ra, rb, 1)
-                xa = fmaf(viewZ, fmaf(rb, q->shX[1], fmaf(ra, q->shX[0], shX2)), q->shX[3]);
-                ya = fmaf(viewZ, fmaf(rb, q->shY[1], fmaf(ra, q->shY[0], shY2)), q->shY[3]);
-                cmp = fmaf(viewZ, fmaf(rb, q->shZ[1], fmaf(ra, q->shZ[0], shZ2)), q->shZ[3]);
+                // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) = viewZ * (affine in ndc) + constant
+                xa = fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), p.hot.shT[0]);
+                ya = fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), p.hot.shT[1]);
+                cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), p.hot.shT[2]);
                 const float xa0 = floorf(xa), ya0 = floorf(ya);
                 sfx = xa - xa0; sfy = ya - ya0;
                 // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
-                const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, q->shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, q->shadowHm3);
+                const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, p.hot.shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, p.hot.shadowHm3);
                 fast = ic == xa0 && jc == ya0;
-                const uint32_t o0 = (uint32_t)fmaf(jc, q->shadowWf, ic) * 4u, o1 = o0 + q->shadowRowBytes, o2 = o1 + q->shadowRowBytes;
-                const float* smap = q->shadow;
+                const uint32_t o0 = (uint32_t)fmaf(jc, p.hot.shadowWf, ic) * 4u, o1 = o0 + p.hot.shadowRowBytes, o2 = o1 + p.hot.shadowRowBytes;
+                const float* smap = p.hot.shadow;
                 sa = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o0);
                 sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
                 sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
             }
+            UR_STAMP(tB);
             // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
-            F3 albedo = f3(0.5f, 0.5f, 0.5f);
-            float ba = 0.5f, bb = 0.1f;
-            if (!(ablate & 16u)) {
-                albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
+            const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
+            float ba, bb;
+            {
                 // bordered coordinates: x in [0.5, W + 0.5] (NdotV is saturated), y clamped likewise (roughness is not)
                 const float x = fmaf(NdotV, (float)kLutW, 0.5f);
                 const float y = __builtin_amdgcn_fmed3f(fmaf(roughness, (float)kLutH, 0.5f), 0.5f, (float)kLutH + 0.5f);
@@ -831,12 +879,12 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
                 bb = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
             }
             F3 irradiance = f3(0.0f, 0.0f, 0.0f);
-            if (IRR_LDS && !(ablate & 16u)) {
-                const float x = fmaf(uN, q->irrNf, 0.5f), y = fmaf(vN, q->irrNf, 0.5f);
+            if (IRR_LDS) {
+                const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
                 const float fx = x - i0, fy = y - j0;
-                const uint32_t E = q->irrN0 + 2u;
-                const float4a* t = irrT + (uint32_t)fmaf(faceN, q->irrEEf, fmaf(j0, q->irrEf, i0));
+                const uint32_t E = p.hot.irrN0 + 2u;
+                const float4a* t = irrT + (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
                 const float4a t00 = t[0], t10 = t[1], t01 = t[E], t11 = t[E + 1];
                 const float wy0 = 1.0f - fy;
                 const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
@@ -846,44 +894,47 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             }
             // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) ----------------------------------------
             const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
-            F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
-            const float hr = rsq(dot(Hv, Hv));
-            const float NdotH = sat(dot(N, Hv) * hr);
-            const float VdotH = dot(V, Hv) * hr; // = (1 + V.L)/|V + L| in [0,1]: saturate is the identity up to rounding
-            const float alpha = roughness * roughness;
-            const float alpha2 = alpha * alpha;
-            const float denom = fmaf(NdotH * NdotH, alpha2 - 1.0f, 1.0f);
-            const float D = alpha2 * rcp(fmaxf(3.14159265f * denom * denom, 1e-4f));
-            float k = roughness + 1.0f;
-            k = (k * k) * 0.125f;
-            const float omk = 1.0f - k;
-            // G / max(4 NdotL NdotV, 1e-4) * D, one reciprocal for the three denominators
-            const float gv = fmaf(NdotV, omk, k), gl = fmaf(NdotL, omk, k);
-            float scs = (ablate & 4u) ? 0.5f : (D * NdotV * NdotL) * rcp(gv * gl * fmaxf(4.0f * NdotL * NdotV, 1e-4f));
-            const float om = 1.0f - VdotH;
-            const float om2 = om * om;
-            float p5 = (ablate & 4u) ? 0.5f : om2 * om2 * om;
+            float scs = 0.0f, p5 = 0.0f;
+            if (wave_direct) { // a wave without a lit pixel has direct = 0 whatever D, G and F are
+                F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
+                const float hr = rsq(dot(Hv, Hv));
+                const float NdotH = sat(dot(N, Hv) * hr);
+                const float VdotH = dot(V, Hv) * hr; // = (1 + V.L)/|V + L| in [0,1]: saturate is the identity up to rounding
+                const float alpha = roughness * roughness;
+                const float alpha2 = alpha * alpha;
+                const float denom = fmaf(NdotH * NdotH, alpha2 - 1.0f, 1.0f);
+                const float D = alpha2 * rcp(fmaxf(3.14159265f * denom * denom, 1e-4f));
+                float k = roughness + 1.0f;
+                k = (k * k) * 0.125f;
+                const float omk = 1.0f - k;
+                // G / max(4 NdotL NdotV, 1e-4) * D, one reciprocal for the three denominators
+                const float gv = fmaf(NdotV, omk, k), gl = fmaf(NdotL, omk, k);
+                scs = (D * NdotV * NdotL) * rcp(gv * gl * fmaxf(4.0f * NdotL * NdotV, 1e-4f));
+                const float om = 1.0f - VdotH;
+                const float om2 = om * om;
+                p5 = om2 * om2 * om;
+            }
             float kdm = 1.0f - metallic;
+            UR_STAMP(tC);
             // the math above is wanted BEFORE the first wait on a gather, not sunk behind it
             asm volatile("" : "+v"(scs), "+v"(p5), "+v"(kdm), "+v"(ba), "+v"(bb), "+v"(irradiance.x), "+v"(irradiance.y), "+v"(irradiance.z));
             __builtin_amdgcn_sched_barrier(0);
             // ---- shadow filter (its taps were issued last: their wait covers every gather) -------------------------------------
             float shadow = 1.0f;
-            if (wave_lit && (ablate & 1u)) shadow = sa.x + sb.y + sc3.z;
-            else if (wave_lit) {
+            if (wave_lit) {
                 // PCF = 1 - 0.25 sum w (cmp > t) with separable weights (1-f, 1, f); then lerp(1, pcf, strength)
                 const float cb = cmp * 0x1p126f;
                 const float wx0 = 1.0f - sfx, wy0 = 1.0f - sfy;
                 const float r0 = fmaf(gt_step(cb, sa.z, negBig), sfx, fmaf(gt_step(cb, sa.x, negBig), wx0, gt_step(cb, sa.y, negBig)));
                 const float r1 = fmaf(gt_step(cb, sb.z, negBig), sfx, fmaf(gt_step(cb, sb.x, negBig), wx0, gt_step(cb, sb.y, negBig)));
                 const float r2 = fmaf(gt_step(cb, sc3.z, negBig), sfx, fmaf(gt_step(cb, sc3.x, negBig), wx0, gt_step(cb, sc3.y, negBig)));
-                shadow = fmaf(fmaf(sfy, r2, fmaf(wy0, r0, r1)), q->shadowNegQuarterStrength, 1.0f);
+                shadow = fmaf(fmaf(sfy, r2, fmaf(wy0, r0, r1)), p.hot.shadowNegQuarterStrength, 1.0f);
                 if (__builtin_expect(__any(!fast), 0)) { // some pixel's footprint touches the border (or lies outside the map)
-                    const bool lit = xa >= -0.5f && ya >= -0.5f && xa <= q->shadowXmax && ya <= q->shadowYmax;
+                    const bool lit = xa >= -0.5f && ya >= -0.5f && xa <= kp->hot.shadowXmax && ya <= kp->hot.shadowYmax;
                     if (!fast) {
                         const float xa0 = floorf(xa), ya0 = floorf(ya);
-                        const float s = shadow_pcf_border_inline(q->shadow, q->shadowWi, q->shadowHi, (int)xa0, (int)ya0, sfx, sfy, cmp);
-                        shadow = mix(1.0f, s, q->shadowStrength);
+                        const float s = shadow_pcf_border_inline(p.hot.shadow, kp->hot.shadowWi, kp->hot.shadowHi, (int)xa0, (int)ya0, sfx, sfy, cmp);
+                        shadow = mix(1.0f, s, kp->hot.shadowStrength);
                     }
                     if (!lit) shadow = 1.0f;
                 }
@@ -891,16 +942,18 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             need(p0a, p0b, p1a, p1b);
             if (!IRR_LDS) need(pia, pib, pia, pib);
             __builtin_amdgcn_sched_barrier(0);
+            UR_STAMP(tD);
             // hipcc has no load of its own in flight here: the DMA for the tile two steps ahead goes into the buffer just read.
             // The vmcnt(0) retires every older vector-memory operation of the wave, in particular the DMA issued at the previous
             // iteration's prefetch point: the tile the NEXT iteration reads is in LDS from here on.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (more2) tile_prefetch<MODE>(kp, q->W, q->rows, src, lane, tx2, ty2, bufBase + parity * kTileBytes);
+            UR_STAMP(tE);
+            UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
             // ---- filter, combine ---------------------------------------------------------------------------------------------------
             const float sh_l = shadow * NdotL;
-            F3 prefiltered = f3(fx0, fy1, fl);
-            if (!(ablate & 2u)) {
+            F3 prefiltered;
+            {
                 CubeTaps t;
                 t.r0 = uint4u{p0a.x, p0a.y, p0a.z, p0a.w}; t.r1 = uint4u{p0b.x, p0b.y, p0b.z, p0b.w}; t.fx = fx0; t.fy = fy0;
                 cube_taps_filter<false>(prefiltered, t, 1.0f - fl);
@@ -918,7 +971,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
         const float F = fmaf(1.0f - F0.ch, p5, F0.ch);                                                        \
         const float direct = fmaf(F, scs - A, A);            /* (1-F) A + F sc */                            \
         const float ambient = fmaf(irradiance.ch, A, prefiltered.ch * fmaf(F0.ch, ba, bb));                   \
-        color.ch = fmaf(direct, q->lightRGB[i] * sh_l, ambient);                                              \
+        color.ch = fmaf(direct, p.hot.lightRGB[i] * sh_l, ambient);                                              \
     }
             UR_CHANNEL(x, 0)
             UR_CHANNEL(y, 1)
@@ -931,20 +984,32 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
         } else {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (more2) tile_prefetch<MODE>(kp, q->W, q->rows, src, lane, tx2, ty2, bufBase + parity * kTileBytes);
+            UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (ty * 4u + row < q->rows) { // false only in the rows a partial bottom tile hangs over the band
+        if (ty * 4u + row < p.hot.rows) { // false only in the rows a partial bottom tile hangs over the band
             half4_t o;
             o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z; o.w = (_Float16)outw;
-            const uint32_t i = (ty * 4u + row) * q->W + tx * 16u + col;
-            st<half4_t>(q->hdr, i * 8u, o);
+            const uint32_t i = (ty * 4u + row) * p.hot.W + tx * 16u + col;
+            st<half4_t>(p.hot.hdr, i * 8u, o);
         }
-        tile += G;
-        if (tile >= q->numTiles) break;
+#ifdef UR_STAMPS
+        UR_STAMP(tF);
+        if (tE != 0) { sum0 += tB - tA; sum1 += tC - tB; sum2 += tD - tC; sum3 += tE - tD; sum4 += tF - tE; iters += 1; }
+        tE = 0;
+#endif
+        if (!more1) break;
+        tile = tile1; tile1 = tile2; // tile2 stays 0xFFFFFFFF when nothing was left to claim
         tx = tx1; ty = ty1; tx1 = tx2; ty1 = ty2;
         parity ^= 1u;
     }
+#undef UR_PREFETCH_POINT
+#ifdef UR_STAMPS
+    if (p.stamps && lane == 0) {
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x * WPB + wave) * 8u;
+        o[0] = sum0; o[1] = sum1; o[2] = sum2; o[3] = sum3; o[4] = sum4; o[5] = iters;
+    }
+#endif
 }
 
 void mat4_mul(const float* a, const float* b, float* o)
@@ -976,9 +1041,19 @@ void launch_tiled(ur_ctx* ctx, const LightingParams& p)
     else hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 4>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
 }
 
+#ifdef UR_STAMPS
+unsigned long long* g_stamps = nullptr;
+constexpr size_t kStampWaves = 8192;
+#endif
+
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk is filled in here */)
 {
+#ifdef UR_STAMPS
+    if (!g_stamps) UR_HIP_TRY(hipMalloc(&g_stamps, kStampWaves * 8 * sizeof(unsigned long long)));
+    UR_HIP_TRY(hipMemsetAsync(g_stamps, 0, kStampWaves * 8 * sizeof(unsigned long long), ctx->stream));
+    p.stamps = g_stamps;
+#endif
     constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
     auto kern = lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB>;
     static bool attr_set = false; // per instantiation
@@ -990,11 +1065,8 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     h.tilesX = p.W / 16u;
     h.numTiles = h.tilesX * ((p.rows + 3u) / 4u);
     const uint32_t groups = std::min<uint32_t>((uint32_t)ctx->cu_count * (WPB == 10 ? 2u : 1u), (h.numTiles + WPB - 1) / WPB);
-    const uint32_t G = groups * WPB; // waves in the grid = tile stride of one wave
-    h.stepX = G % h.tilesX;
-    h.stepY = G / h.tilesX;
-    static const int ablate = env_int("UR_LIGHTING_ABLATE", 0);
-    h.ablate = (uint32_t)ablate;
+    // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
+    h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
     hipLaunchKernelGGL(kern, dim3(groups), dim3(64 * WPB), lds, ctx->stream, p);
     return UR_OK;
 }
@@ -1012,6 +1084,16 @@ int launch_stream(ur_ctx* ctx, const LightingParams& p)
 
 } // namespace
 
+#ifdef UR_STAMPS
+// diagnostic builds only: the per-wave segment sums of the last streaming launch (8 u64 per wave)
+extern "C" int ur_debug_stamps(unsigned long long* out, unsigned int waves)
+{
+    if (!g_stamps || waves > kStampWaves) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpy(out, g_stamps, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace ur {
 
 int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_constants* K, const ur_half4* A, const ur_half4* B,
@@ -1027,12 +1109,14 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     p.hdr = reinterpret_cast<half4_t*>(hdr);
     p.srgb = ctx->srgb_table;
     bool shadows = false;
+    float ortho_err = 0.0f; // departure of (float3x3)ViewInverse from an orthonormal matrix
     if (mode != UR_MODE_SKY) {
         // the view matrix must be rigid: rows of (float3x3)ViewInverse orthonormal
         const float* VI = S->ViewInverse;
         for (int i = 0; i < 3; ++i)
             for (int j = i; j < 3; ++j) {
                 const float d = VI[i * 4] * VI[j * 4] + VI[i * 4 + 1] * VI[j * 4 + 1] + VI[i * 4 + 2] * VI[j * 4 + 2];
+                ortho_err = std::fmax(ortho_err, std::fabs(d - (i == j ? 1.0f : 0.0f)));
                 if (std::fabs(d - (i == j ? 1.0f : 0.0f)) > 1e-3f) {
                     set_error("ViewInverse is not a rigid transform (row %d . row %d = %g)", i, j, d);
                     return UR_EUNSUPPORTED;
@@ -1121,7 +1205,10 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     // ---- streaming kernel when the band is a whole number of 16-pixel tile columns; the per-tile kernel otherwise -----------
     static const int use_stream = env_int("UR_LIGHTING_STREAM", 1);
     bool streamed = false;
-    if (use_stream && mode != UR_MODE_SKY && w % 16u == 0 && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
+    const uint64_t n_tiles = (uint64_t)(w / 16u) * ((rows + 3u) / 4u);
+    const uint64_t magic_err = w >= 16u ? ((1ull << 32) / (w / 16u) + 1ull) * (w / 16u) - (1ull << 32) : 0;
+    // (the streaming kernel takes its dot products in world space: the rotation must be orthonormal to rounding)
+    if (use_stream && mode != UR_MODE_SKY && ortho_err <= 1e-5f && w % 16u == 0 && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
         bool ok = true;
         StreamHot& h = p.hot;
         if (shadows) {
@@ -1129,14 +1216,16 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
             // su * W - 0.5, sv * H - 0.5 and depth - bias are affine in viewZ * (ra, rb, 1)
             ok = p.SQ[3] == 0.0f && p.SQ[7] == 0.0f && p.SQ[11] == 0.0f && p.ST[3] == 1.0f;
             const double hw = 0.5 * p.shadowW, hh = 0.5 * p.shadowH;
+            const double sc[3] = {hw, -hh, 1.0}; // clip -> (texel x, texel y, depth)
             for (int k = 0; k < 3; ++k) {
-                h.shX[k] = (float)(p.SQ[4 * k + 0] * hw);
-                h.shY[k] = (float)(p.SQ[4 * k + 1] * -hh);
-                h.shZ[k] = p.SQ[4 * k + 2];
+                // clip[k] = viewZ * (ra * SQ[k] + rb * SQ[4 + k] + SQ[8 + k]) + ST[k], ra = ndc.x / P11, rb = -ndc.y / P22
+                h.shA[k] = (float)(p.SQ[k] * sc[k] * p.invP11);
+                h.shB[k] = (float)(p.SQ[4 + k] * sc[k] * -(double)p.invP22);
+                h.shC[k] = (float)(p.SQ[8 + k] * sc[k]);
             }
-            h.shX[3] = (float)(p.ST[0] * hw + hw - 0.5);
-            h.shY[3] = (float)(p.ST[1] * -hh + hh - 0.5);
-            h.shZ[3] = p.ST[2] - p.shadowBias;
+            h.shT[0] = (float)(p.ST[0] * hw + hw - 0.5);
+            h.shT[1] = (float)(p.ST[1] * -hh + hh - 0.5);
+            h.shT[2] = p.ST[2] - p.shadowBias;
             h.shadowXmax = p.shadowW - 0.5f;
             h.shadowYmax = p.shadowH - 0.5f;
             h.shadowWi = p.shadowWi; h.shadowHi = p.shadowHi;
@@ -1160,7 +1249,17 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
             h.irrOfff = (float)p.irrOffset0; h.irrRowBytes = iE * 8u;
             h.env = p.env; h.hdr = p.hdr;
             for (int k = 0; k < 9; ++k) h.R[k] = p.R[k];
-            for (int k = 0; k < 3; ++k) { h.L[k] = p.L[k]; h.lightRGB[k] = p.lightRGB[k]; }
+            for (int k = 0; k < 3; ++k) {
+                h.Lw[k] = (p.L[0] * p.R[k] + p.L[1] * p.R[3 + k]) + p.L[2] * p.R[6 + k]; // view-space L rotated like every other vector
+                h.WA[k] = p.invP11 * p.R[k];
+                h.WB[k] = -p.invP22 * p.R[3 + k];
+                h.WC[k] = p.R[6 + k];
+                h.lightRGB[k] = p.lightRGB[k];
+            }
+            {   // largest sphere depth of the frame: (Near/R) * |(vx, vy, 1)| at the ndc corner, with a margin of a few ulp
+                const double vx = p.skyInvP11, vy = p.skyInvP22;
+                h.skyDepthMax = (float)(p.skyNearOverR * std::sqrt(vx * vx + vy * vy + 1.0) * (1.0 + 1e-5));
+            }
             streamed = true;
             const LightingParams& q = p;
             const bool irr_lds = p.irrN0 <= 2u;

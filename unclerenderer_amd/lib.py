@@ -6,11 +6,14 @@ entry points raises — build it with `python -m unclerenderer_amd.build` (hipcc
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "_build" / "libur_hotpath.so"
+if os.environ.get("UR_HOTPATH_LIB"):  # diagnostic builds (e.g. the in-kernel-stamps build of tools/stamps_lighting.py)
+    _LIB_PATH = Path(os.environ["UR_HOTPATH_LIB"]).resolve()
 
 UR_OK = 0
 UR_EINVAL, UR_EHIP, UR_ENOMEM, UR_ENODEVICE, UR_EUNSUPPORTED = -1, -2, -3, -4, -5
