@@ -10,8 +10,8 @@
 // MI355X shape: 256-thread workgroups (4 x wave64). The workgroup's 256 AABBs (8 KB) are staged through LDS with
 // fully-coalesced 16-byte loads, then each lane reads its own min/max pair. Visibility is a wave ballot: lane 0 keeps
 // the 64-bit mask, popcounts give per-wave and per-workgroup counts. Compaction is deterministic (ascending index, no
-// atomic append): pass 1 stores per-wave masks and per-workgroup counts, pass 2 takes the exclusive prefix of the
-// workgroup counts and scatters index = base + mbcnt(mask). Up to 256 instances (Sponza 25, pica_pica 170) both passes
+// atomic append): pass 1 stores per-wave masks and per-workgroup counts, pass 2 (one thread per mask) takes the exclusive
+// prefix of the counts and writes out the set bits of its mask. Up to 256 instances (Sponza 25, pica_pica 170) both passes
 // run inside one launch.
 
 #include "ur_internal.h"
@@ -170,23 +170,40 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
     }
 }
 
+// Pass 2: one thread per wave mask (64 instances), one workgroup per 256 masks = 64 cull blocks. The workgroup's base is
+// the sum of the block counts in front of it (a few loads per thread), a thread's offset the exclusive scan of the mask
+// popcounts inside the workgroup; the few set bits of a mask are written out in ascending order.
 __global__ __launch_bounds__(256) void compact_kernel(CullParams C, uint32_t num_blocks)
 {
-    __shared__ uint32_t spart[4];
-    __shared__ uint64_t smask[4];
+    __shared__ uint32_t spart[4], swave[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // exclusive prefix of the block counts in front of this block
+    const uint32_t num_masks = num_blocks * 4u, mi = blockIdx.x * 256u + tid;
+    const uint64_t m = mi < num_masks ? C.wave_masks[mi] : 0ull;
     uint32_t s = 0;
-    for (uint32_t b = tid; b < blockIdx.x; b += 256u) s += C.block_counts[b];
+    for (uint32_t b = tid; b < blockIdx.x * 64u; b += 256u) s += C.block_counts[b];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    // inclusive scan of the popcounts across the wave, then across the four waves
+    const uint32_t c = __popcll(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += up;
+    }
     if (lane == 0) spart[wave] = s;
-    if (tid < 4) smask[tid] = C.wave_masks[(size_t)blockIdx.x * 4u + tid];
+    if (lane == 63) swave[wave] = incl;
     __syncthreads();
-    const uint32_t base = spart[0] + spart[1] + spart[2] + spart[3];
-    ScatterBlock(C, blockIdx.x, smask, base);
-    if (blockIdx.x == num_blocks - 1u && tid == 0)
-        *C.visible_count = base + __popcll(smask[0]) + __popcll(smask[1]) + __popcll(smask[2]) + __popcll(smask[3]);
+    uint32_t at = spart[0] + spart[1] + spart[2] + spart[3] + incl - c;
+    for (uint32_t w = 0; w < wave; ++w) at += swave[w];
+    uint64_t bits = m;
+    const uint32_t first = mi * 64u + C.index_base;
+    while (bits) {
+        const uint32_t b = __builtin_ctzll(bits);
+        C.visible_idx[at++] = first + b;
+        bits &= bits - 1ull;
+    }
+    if (mi == num_masks - 1u) *C.visible_count = at;
 }
 
 __global__ void zero_count_kernel(uint32_t* p) { *p = 0; }
@@ -239,7 +256,7 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
     hipLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, P);
     UR_HIP_TRY(hipGetLastError());
     if (visible_idx) {
-        hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P, blocks);
+        hipLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, P, blocks);
         UR_HIP_TRY(hipGetLastError());
     }
     return UR_OK;

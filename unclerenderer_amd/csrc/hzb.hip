@@ -107,6 +107,66 @@ __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
     }
 }
 
+// ---- the tail of the chain in ONE single-workgroup launch ----------------------------------------------------------------
+// Once a mip has <= 16384 texels every remaining level fits in LDS, and the reference's further dispatches (<= 4 mips
+// each) are a few microseconds of launch latency apiece for microseconds of work in total. The values are those of the
+// reference's grouping all the same: a level whose index is a multiple of four is the FIRST level of a reference dispatch
+// — it reads its parent through clamped 2x2 footprints (SampleDepth, BuildHZB.hlsl:34-39) — every other level takes the
+// 2x2 of its parent's lanes, where an out-of-range parent lane holds 1.0 if the parent was a first level and 0.0
+// otherwise (BuildHZB.hlsl:47,81,104).
+constexpr uint32_t kTailMaxLevels = 12, kTailTexels = 16384;
+struct HzbTail {
+    const float* src; // mip first_mip - 1 (global memory, written by the previous launch)
+    uint32_t SW, SH, first_mip, levels;
+    float* dst[kTailMaxLevels];
+    uint32_t W[kTailMaxLevels], H[kTailMaxLevels];
+};
+
+__global__ __launch_bounds__(1024) void hzb_tail_kernel(HzbTail p)
+{
+    __shared__ float bufA[kTailTexels], bufB[kTailTexels / 2];
+    const uint32_t tid = threadIdx.x;
+    {   // first level of the tail: a first-of-dispatch level by construction (first_mip % 4 == 0), parent in global memory
+        const uint32_t W = p.W[0], H = p.H[0];
+        for (uint32_t i = tid; i < W * H; i += 1024u) {
+            const uint32_t y = i / W, x = i - y * W;
+            const uint32_t x0 = min(2u * x, p.SW - 1u), x1 = min(2u * x + 1u, p.SW - 1u);
+            const uint32_t y0 = min(2u * y, p.SH - 1u), y1 = min(2u * y + 1u, p.SH - 1u);
+            const float v = min4(p.src[(size_t)y0 * p.SW + x0], p.src[(size_t)y0 * p.SW + x1], p.src[(size_t)y1 * p.SW + x0], p.src[(size_t)y1 * p.SW + x1]);
+            bufA[i] = v;
+            p.dst[0][i] = v;
+        }
+    }
+    __syncthreads();
+    for (uint32_t l = 1; l < p.levels; ++l) { // uniform
+        const float* par = (l & 1u) ? bufA : bufB;
+        float* cur = (l & 1u) ? bufB : bufA;
+        const uint32_t W = p.W[l], H = p.H[l], PW = p.W[l - 1], PH = p.H[l - 1];
+        const uint32_t m = p.first_mip + l;
+        const bool first = (m & 3u) == 0u;                     // first level of a reference dispatch: clamped reads
+        const float fill = ((m - 1u) & 3u) == 0u ? 1.0f : 0.0f; // what an out-of-range parent lane holds otherwise
+        for (uint32_t i = tid; i < W * H; i += 1024u) {
+            const uint32_t y = i / W, x = i - y * W;
+            float v;
+            if (first) {
+                const uint32_t x0 = min(2u * x, PW - 1u), x1 = min(2u * x + 1u, PW - 1u);
+                const uint32_t y0 = min(2u * y, PH - 1u), y1 = min(2u * y + 1u, PH - 1u);
+                v = min4(par[y0 * PW + x0], par[y0 * PW + x1], par[y1 * PW + x0], par[y1 * PW + x1]);
+            } else {
+                const uint32_t x0 = 2u * x, x1 = x0 + 1u, y0 = 2u * y, y1 = y0 + 1u;
+                const float a = par[y0 * PW + x0]; // (2x, 2y) is always in range
+                const float b = x1 < PW ? par[y0 * PW + x1] : fill;
+                const float c = y1 < PH ? par[y1 * PW + x0] : fill;
+                const float d = (x1 < PW && y1 < PH) ? par[y1 * PW + x1] : fill;
+                v = min4(a, b, c, d);
+            }
+            cur[i] = v;
+            p.dst[l][i] = v;
+        }
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 namespace ur {
@@ -115,9 +175,26 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
                      uint32_t mip_count)
 {
     // Same grouping as the reference's while-loop (DeferredRenderer.cpp:1046-1207): <=4 mips per launch, first launch
-    // reads the depth buffer with clamped 2x2 footprints, later launches read the last mip of the previous launch.
+    // reads the depth buffer with clamped 2x2 footprints, later launches read the last mip of the previous launch —
+    // until the remaining levels fit one workgroup's LDS: those run in a single launch with the same values.
     uint32_t mip = 0;
     while (mip < mip_count) {
+        if (mip > 0 && (uint64_t)mips[mip].width * mips[mip].height <= kTailTexels && mip_count - mip <= kTailMaxLevels) {
+            HzbTail t{};
+            t.src = hzb + mips[mip - 1].offset;
+            t.SW = mips[mip - 1].width;
+            t.SH = mips[mip - 1].height;
+            t.first_mip = mip;
+            t.levels = mip_count - mip;
+            for (uint32_t k = 0; k < t.levels; ++k) {
+                t.dst[k] = hzb + mips[mip + k].offset;
+                t.W[k] = mips[mip + k].width;
+                t.H[k] = mips[mip + k].height;
+            }
+            hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(1024), 0, ctx->stream, t);
+            UR_HIP_TRY(hipGetLastError());
+            break;
+        }
         const uint32_t n = (mip_count - mip) < 4u ? (mip_count - mip) : 4u;
         HzbDispatch d{};
         if (mip == 0) {
