@@ -715,11 +715,15 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     const float negBig = vreg(-0x1p126f);
     // Launch constants of the FMA-dense parts as VGPR operands: two neighbouring VALU instructions that both read an SGPR
     // cannot share an issue slot (tools/microbench/valu_rate4.hip), and a VOP3 reads one SGPR at most.
-    float R[9], WC[3], shC[3];
+    float R[9], WC[3], shC[3], shT[3], lightRGB[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = vreg(p.hot.R[k]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); }
+    for (int k = 0; k < 3; ++k) {
+        WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); shT[k] = vreg(p.hot.shT[k]); lightRGB[k] = vreg(p.hot.lightRGB[k]);
+    }
+    // this lane's pixel inside a tile, as a byte offset into the HDR band (the tile origin is added per iteration)
+    const uint32_t laneHdr = (row * p.hot.W + col) * 8u;
 
     // ---- prologue: the wave's two static tiles in flight, wait for both --------------------------------------------------
     if (have0) {
@@ -847,9 +851,9 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             bool fast = true;
             if (wave_lit) {
                 // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) = viewZ * (affine in ndc) + constant
-                xa = fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), p.hot.shT[0]);
-                ya = fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), p.hot.shT[1]);
-                cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), p.hot.shT[2]);
+                xa = fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), shT[0]);
+                ya = fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), shT[1]);
+                cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), shT[2]);
                 const float xa0 = floorf(xa), ya0 = floorf(ya);
                 sfx = xa - xa0; sfy = ya - ya0;
                 // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
@@ -954,12 +958,24 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             const float sh_l = shadow * NdotL;
             F3 prefiltered;
             {
-                CubeTaps t;
-                t.r0 = uint4u{p0a.x, p0a.y, p0a.z, p0a.w}; t.r1 = uint4u{p0b.x, p0b.y, p0b.z, p0b.w}; t.fx = fx0; t.fy = fy0;
-                cube_taps_filter<false>(prefiltered, t, 1.0f - fl);
-                t.r0 = uint4u{p1a.x, p1a.y, p1a.z, p1a.w}; t.r1 = uint4u{p1b.x, p1b.y, p1b.z, p1b.w}; t.fx = fx1; t.fy = fy1;
-                cube_taps_filter<true>(prefiltered, t, fl);
+                // The 24 mixed-precision FMAs below cannot share an issue slot with anything (tools/microbench/valu_rate4.hip):
+                // a weight computed BETWEEN two of them costs a slot of its own, computed next to another weight half of one.
+                const float s0 = 1.0f - fl;
+                float a1 = fy0 * s0, a0 = s0 - a1, b1 = fy1 * fl, b0 = fl - b1;
+                float a10 = a0 * fx0, a00 = a0 - a10, a11 = a1 * fx0, a01 = a1 - a11;
+                float b10 = b0 * fx1, b00 = b0 - b10, b11 = b1 * fx1, b01 = b1 - b11;
+                asm volatile("" : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11));
+                float x = mul_lo(p0a.x, a00), y = mul_hi(p0a.x, a00), z = mul_lo(p0a.y, a00);
+                x = mix_lo(x, p0a.z, a10); y = mix_hi(y, p0a.z, a10); z = mix_lo(z, p0a.w, a10);
+                x = mix_lo(x, p0b.x, a01); y = mix_hi(y, p0b.x, a01); z = mix_lo(z, p0b.y, a01);
+                x = mix_lo(x, p0b.z, a11); y = mix_hi(y, p0b.z, a11); z = mix_lo(z, p0b.w, a11);
+                x = mix_lo(x, p1a.x, b00); y = mix_hi(y, p1a.x, b00); z = mix_lo(z, p1a.y, b00);
+                x = mix_lo(x, p1a.z, b10); y = mix_hi(y, p1a.z, b10); z = mix_lo(z, p1a.w, b10);
+                x = mix_lo(x, p1b.x, b01); y = mix_hi(y, p1b.x, b01); z = mix_lo(z, p1b.y, b01);
+                x = mix_lo(x, p1b.z, b11); y = mix_hi(y, p1b.z, b11); z = mix_lo(z, p1b.w, b11);
+                prefiltered = f3(x, y, z);
                 if (!IRR_LDS) {
+                    CubeTaps t;
                     t.r0 = uint4u{pia.x, pia.y, pia.z, pia.w}; t.r1 = uint4u{pib.x, pib.y, pib.z, pib.w}; t.fx = fxi; t.fy = fyi;
                     cube_taps_filter<false>(irradiance, t, 1.0f); // irrFrac == 0 in this kernel
                 }
@@ -971,7 +987,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
         const float F = fmaf(1.0f - F0.ch, p5, F0.ch);                                                        \
         const float direct = fmaf(F, scs - A, A);            /* (1-F) A + F sc */                            \
         const float ambient = fmaf(irradiance.ch, A, prefiltered.ch * fmaf(F0.ch, ba, bb));                   \
-        color.ch = fmaf(direct, p.hot.lightRGB[i] * sh_l, ambient);                                              \
+        color.ch = fmaf(direct, lightRGB[i] * sh_l, ambient);                                              \
     }
             UR_CHANNEL(x, 0)
             UR_CHANNEL(y, 1)
@@ -990,8 +1006,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
         if (ty * 4u + row < p.hot.rows) { // false only in the rows a partial bottom tile hangs over the band
             half4_t o;
             o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z; o.w = (_Float16)outw;
-            const uint32_t i = (ty * 4u + row) * p.hot.W + tx * 16u + col;
-            st<half4_t>(p.hot.hdr, i * 8u, o);
+            st<half4_t>(p.hot.hdr, ((ty * 4u) * p.hot.W + tx * 16u) * 8u + laneHdr, o);
         }
 #ifdef UR_STAMPS
         UR_STAMP(tF);
