@@ -913,7 +913,9 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
                 const float omk = 1.0f - k;
                 // G / max(4 NdotL NdotV, 1e-4) * D, one reciprocal for the three denominators
                 const float gv = fmaf(NdotV, omk, k), gl = fmaf(NdotL, omk, k);
-                scs = (D * NdotV * NdotL) * rcp(gv * gl * fmaxf(4.0f * NdotL * NdotV, 1e-4f));
+                // max(4 x, 1e-4) = 4 max(x, 1e-4 / 4) exactly (power-of-two scaling)
+                const float nvl = NdotV * NdotL;
+                scs = (D * nvl) * rcp((gv * gl) * (4.0f * fmaxf(nvl, 1e-4f * 0.25f)));
                 const float om = 1.0f - VdotH;
                 const float om2 = om * om;
                 p5 = om2 * om2 * om;
@@ -980,19 +982,22 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
                     cube_taps_filter<false>(irradiance, t, 1.0f); // irrFrac == 0 in this kernel
                 }
             }
-            F3 color;
+            // ambient = irradiance * (1 - metallic) * albedo + prefiltered * (F0 * brdf.x + brdf.y)
+            const F3 A = f3(kdm * albedo.x, kdm * albedo.y, kdm * albedo.z); // diffuse weight, also irradiance's
+            F3 color = f3(fmaf(irradiance.x, A.x, prefiltered.x * fmaf(F0.x, ba, bb)), fmaf(irradiance.y, A.y, prefiltered.y * fmaf(F0.y, ba, bb)),
+                          fmaf(irradiance.z, A.z, prefiltered.z * fmaf(F0.z, ba, bb)));
+            if (wave_direct) { // + ((1 - F) A + F sc) * light * shadow * N.L, which is zero in every lane of an unlit wave
 #define UR_CHANNEL(ch, i)                                                                                     \
     {                                                                                                         \
-        const float A = kdm * albedo.ch;                     /* (1 - metallic) * albedo: diffuse weight, also irradiance's */ \
         const float F = fmaf(1.0f - F0.ch, p5, F0.ch);                                                        \
-        const float direct = fmaf(F, scs - A, A);            /* (1-F) A + F sc */                            \
-        const float ambient = fmaf(irradiance.ch, A, prefiltered.ch * fmaf(F0.ch, ba, bb));                   \
-        color.ch = fmaf(direct, lightRGB[i] * sh_l, ambient);                                              \
+        const float direct = fmaf(F, scs - A.ch, A.ch);                                                       \
+        color.ch = fmaf(direct, lightRGB[i] * sh_l, color.ch);                                                \
     }
-            UR_CHANNEL(x, 0)
-            UR_CHANNEL(y, 1)
-            UR_CHANNEL(z, 2)
+                UR_CHANNEL(x, 0)
+                UR_CHANNEL(y, 1)
+                UR_CHANNEL(z, 2)
 #undef UR_CHANNEL
+            }
             if (!sky) {
                 out = f3(h2f_lo(gd.x) + color.x, h2f_hi(gd.x) + color.y, h2f_lo(gd.y) + color.z);
                 outw = h2f_hi(gd.y) + 1.0f;
@@ -1221,8 +1226,11 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     bool streamed = false;
     const uint64_t n_tiles = (uint64_t)(w / 16u) * ((rows + 3u) / 4u);
     const uint64_t magic_err = w >= 16u ? ((1ull << 32) / (w / 16u) + 1ull) * (w / 16u) - (1ull << 32) : 0;
-    // (the streaming kernel takes its dot products in world space: the rotation must be orthonormal to rounding)
-    if (use_stream && mode != UR_MODE_SKY && ortho_err <= 1e-5f && w % 16u == 0 && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
+    // (the streaming kernel takes its dot products in world space: the rotation must be orthonormal to rounding; its tile DMA
+    // moves 16 bytes per lane: 16-byte-aligned band buffers)
+    const uintptr_t align_bits = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
+                                 reinterpret_cast<uintptr_t>(p.depth) | reinterpret_cast<uintptr_t>(p.hdr);
+    if (use_stream && mode != UR_MODE_SKY && (align_bits & 15u) == 0 && ortho_err <= 1e-5f && w % 16u == 0 && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
         bool ok = true;
         StreamHot& h = p.hot;
         if (shadows) {
