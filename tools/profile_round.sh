@@ -4,7 +4,7 @@
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extras"
+B="python3 $R/bench.py --steps 300 --warmup 200 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_${tag}_trace" -- $B > "$R/gpurun_out/prof_${tag}_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/prof_${tag}_fetch" -- $B > "$R/gpurun_out/prof_${tag}_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/prof_${tag}_write" -- $B > "$R/gpurun_out/prof_${tag}_write.log" 2>&1

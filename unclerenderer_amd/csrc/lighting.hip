@@ -659,38 +659,6 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     float2* lut = reinterpret_cast<float2*>(smem + kLdsLut);
     uint32_t* work = reinterpret_cast<uint32_t*>(smem + kLdsWork);
 
-    // ---- stage the tables (once per workgroup): every load is issued before the first result is converted, so the
-    //      workgroup pays one memory latency, not one per loop trip -----------------------------------------------------
-    {
-        constexpr uint32_t T = 64 * WPB, kLutN = kLutE * (kLutH + 2u), kLutTrips = (kLutN + T - 1) / T;
-        uint32_t lt[kLutTrips];
-#pragma unroll
-        for (uint32_t k = 0; k < kLutTrips; ++k) {
-            const uint32_t i = min(threadIdx.x + k * T, kLutN - 1u);
-            const uint32_t by = i / kLutE, bx = i - by * kLutE;
-            const uint32_t sx = min(max(bx, 1u), kLutW) - 1u, sy = min(max(by, 1u), kLutH) - 1u; // border = clamp addressing
-            lt[k] = p.lut[sy * kLutW + sx];
-        }
-        const float sv = threadIdx.x < 256u ? p.srgb[threadIdx.x] : 0.0f;
-        half4_t ih = {};
-        const uint32_t irrE = p.irrN0 + 2u, irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
-        if (threadIdx.x < irrCount) ih = p.env[p.irrOffset0 + threadIdx.x];
-        if (threadIdx.x == 0) *work = 2u * WPB;
-        if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
-        if (threadIdx.x < irrCount) irrT[threadIdx.x] = float4a{(float)ih.x, (float)ih.y, (float)ih.z, 0.0f};
-        if (threadIdx.x < 17u) {
-            const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
-            const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
-            mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * E), (float)p.envMipOffset[m], E * 8u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kLutTrips; ++k) {
-            const uint32_t i = threadIdx.x + k * T;
-            if (i < kLutN) lut[i] = float2{(float)(lt[k] & 0xFFFFu) / 65535.0f, (float)(lt[k] >> 16) / 65535.0f}; // the oracle's texel values
-        }
-    }
-    __syncthreads();
-
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform by construction: keeps the tile walk on the scalar ALU
     const uint32_t G = gridDim.x * WPB;
@@ -725,12 +693,44 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     // this lane's pixel inside a tile, as a byte offset into the HDR band (the tile origin is added per iteration)
     const uint32_t laneHdr = (row * p.hot.W + col) * 8u;
 
-    // ---- prologue: the wave's two static tiles in flight, wait for both --------------------------------------------------
+    // ---- the wave's two static tiles go in flight first: their HBM latency runs under the table staging below -------------
     if (have0) {
         tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
         if (tile1 < p.hot.numTiles) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- stage the tables (once per workgroup): every load is issued before the first result is converted, so the
+    //      workgroup pays one memory latency, not one per loop trip -----------------------------------------------------
+    {
+        constexpr uint32_t T = 64 * WPB, kLutN = kLutE * (kLutH + 2u), kLutTrips = (kLutN + T - 1) / T;
+        uint32_t lt[kLutTrips];
+#pragma unroll
+        for (uint32_t k = 0; k < kLutTrips; ++k) {
+            const uint32_t i = min(threadIdx.x + k * T, kLutN - 1u);
+            const uint32_t by = i / kLutE, bx = i - by * kLutE;
+            const uint32_t sx = min(max(bx, 1u), kLutW) - 1u, sy = min(max(by, 1u), kLutH) - 1u; // border = clamp addressing
+            lt[k] = p.lut[sy * kLutW + sx];
+        }
+        const float sv = threadIdx.x < 256u ? p.srgb[threadIdx.x] : 0.0f;
+        half4_t ih = {};
+        const uint32_t irrE = p.irrN0 + 2u, irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
+        if (threadIdx.x < irrCount) ih = p.env[p.irrOffset0 + threadIdx.x];
+        if (threadIdx.x == 0) *work = 2u * WPB;
+        if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
+        if (threadIdx.x < irrCount) irrT[threadIdx.x] = float4a{(float)ih.x, (float)ih.y, (float)ih.z, 0.0f};
+        if (threadIdx.x < 17u) {
+            const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
+            const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
+            mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * E), (float)p.envMipOffset[m], E * 8u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kLutTrips; ++k) {
+            const uint32_t i = threadIdx.x + k * T;
+            if (i < kLutN) lut[i] = float2{(float)(lt[k] & 0xFFFFu) / 65535.0f, (float)(lt[k] >> 16) / 65535.0f}; // the oracle's texel values
+        }
+    }
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two tile DMAs
 
     uint32_t parity = 0;
 // (macro: the statement appears in the shading path and in the all-sky path)
