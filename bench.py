@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--async-compute", action="store_true",
                     help="put the visibility passes on the graph's async-compute stream. Off by default: the streaming lighting kernel "
                          "keeps every CU's register file full, so the passes no longer run beside it (measured: same frame time)")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each frame's HDR all-gather before the next frame starts")
     ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 1M-instance cull and iid side measurements")
@@ -67,10 +68,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # UR_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices;
+    # RCCL refuses that). The measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("UR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     W, H, N = args.width, args.height, world
     if H % N != 0:
@@ -163,11 +172,20 @@ def main():
         s = sets[k % ring]
         # one frame in eight carries the event pair: an event record costs ~4 us of queue time on this stack, which would
         # otherwise inflate every timed frame by ~6 %
+        if s.get("gather") is not None:  # this buffer set's previous all-gather must have finished before it is shaded into again
+            s["gather"].wait()
+            s["gather"] = None
         frame.render(s["res"], cull_consts, fc.scene, fc.sky, timed_flags if (timed and k % 8 == 0) else flags)
         if N > 1:
-            urdist.allgather_hdr(s["hdr_full"], s["hdr_band"])
+            # RCCL all-gather of the bands on the communication stream, behind this frame's passes; the next frames (other
+            # buffer sets of the ring) are shaded while it runs — frames in flight, as the reference keeps three
+            s["gather"] = urdist.allgather_hdr(s["hdr_full"], s["hdr_band"], async_op=not args.sync_gather)
 
     def fence():
+        for s in sets:
+            if s.get("gather") is not None:
+                s["gather"].wait()
+                s["gather"] = None
         if args.async_compute:
             frame.join_async()
         torch.cuda.synchronize()
@@ -227,7 +245,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"Sponza {W}x{H} full pipeline: cull(25) + BuildHZB({lay.count} mips) + DeferredLighting+Sky fused"
-                        + (f", {N} row bands + RCCL all-gather of HDR" if N > 1 else ""),
+                        + (f", {N} row bands + RCCL all-gather of HDR" + (" (overlapped with the next frames)" if not args.sync_gather else "") if N > 1 else ""),
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",

@@ -34,6 +34,12 @@ def _worker(rank, world, port, w, h, n_inst, out_dir):
         band = o.sky_atmosphere(fc.sky, g.depth, lit, w, h, plan.row0, plan.rows)
         hdr_full = torch.zeros((h, w, 4), dtype=torch.int16)
         urdist.allgather_hdr(hdr_full, torch.from_numpy(band.view(np.int16)))
+        # the overlapped form bench.py uses: a Work handle, waited for before the buffers are touched again
+        hdr_async = torch.zeros((h, w, 4), dtype=torch.int16)
+        work = urdist.allgather_hdr(hdr_async, torch.from_numpy(band.view(np.int16)), async_op=True)
+        assert work is not None
+        work.wait()
+        assert torch.equal(hdr_async, hdr_full)
         # cull: instance ranges + replicated HZB
         depth_full = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 17).depth
         mips, total = o.hzb_layout(w, h)

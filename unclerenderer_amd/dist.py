@@ -39,14 +39,21 @@ def plan_instances(count: int, world: int, rank: int) -> tuple[int, int]:
     return rank * count // world, (rank + 1) * count // world
 
 
-def allgather_hdr(hdr_full: torch.Tensor, band: torch.Tensor, group=None) -> None:
-    """hdr_full: (H, W, 4) 16-bit tensor on every rank; band: this rank's (H/N, W, 4) rows. One collective."""
+def allgather_hdr(hdr_full: torch.Tensor, band: torch.Tensor, group=None, async_op: bool = False):
+    """hdr_full: (H, W, 4) 16-bit tensor on every rank; band: this rank's (H/N, W, 4) rows. One collective.
+
+    async_op=True returns the collective's Work handle (None when there is nothing to exchange): the gather runs on the
+    backend's communication stream behind everything already queued on the current stream, and `work.wait()` makes the
+    current stream wait for it — the caller overlaps it with the next frame's passes and waits before it touches
+    `hdr_full` or `band` again."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         if band.data_ptr() != hdr_full.data_ptr():
             hdr_full.copy_(band.view_as(hdr_full))
-        return
+        return None
     # transported as bytes: neither RCCL nor gloo has a 16-bit integer type, and the payload is opaque fp16 bit patterns
-    dist.all_gather_into_tensor(hdr_full.view(torch.uint8).view(-1), band.contiguous().view(torch.uint8).view(-1), group=group)
+    work = dist.all_gather_into_tensor(hdr_full.view(torch.uint8).view(-1), band.contiguous().view(torch.uint8).view(-1), group=group,
+                                       async_op=async_op)
+    return work if async_op else None
 
 
 def allgather_visible(visible_idx: torch.Tensor, visible_count: torch.Tensor, group=None) -> tuple[torch.Tensor, int]:
