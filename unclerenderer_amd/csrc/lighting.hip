@@ -627,7 +627,6 @@ __device__ __forceinline__ float gt_step(float cmpBig, float t, float negBig /* 
 }
 
 struct __attribute__((aligned(16))) MipEntry { float Nf, Ef, EEf, offf; uint32_t rowBytes, pad0, pad1, pad2; };
-constexpr uint32_t kLdsMipBytes = 17 * 32; // 16 mips + the duplicated last entry
 
 // input-only "these registers are needed here": hipcc puts the s_waitcnt of pending loads in front of the statement
 __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u32x4_t& c, const u32x4_t& d)
@@ -661,7 +660,6 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform by construction: keeps the tile walk on the scalar ALU
-    const uint32_t G = gridDim.x * WPB;
     // Tile schedule: block-cyclic over the workgroups (round r gives workgroup b the WPB consecutive tiles starting at
     // (r * groups + b) * WPB), dynamic inside the workgroup: a wave takes its next tile from a counter in LDS. The SIMD's
     // oldest-first arbitration lets some waves of a workgroup run up to twice as fast as others (measured with in-kernel
@@ -726,7 +724,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
 #pragma unroll
         for (uint32_t k = 0; k < kLutTrips; ++k) {
             const uint32_t i = threadIdx.x + k * T;
-            if (i < kLutN) lut[i] = float2{(float)(lt[k] & 0xFFFFu) / 65535.0f, (float)(lt[k] >> 16) / 65535.0f}; // the oracle's texel values
+            // unorm16 -> float by the reciprocal: within one ulp of the oracle's quotient, a tenth of the instructions
+            if (i < kLutN) lut[i] = float2{(float)(lt[k] & 0xFFFFu) * (1.0f / 65535.0f), (float)(lt[k] >> 16) * (1.0f / 65535.0f)};
         }
     }
     __syncthreads();
@@ -867,7 +866,10 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             }
             UR_STAMP(tB);
             // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
-            const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
+            // table byte offsets straight from the packed texel: (c << 2) & 0x3FC, (c >> 6) & 0x3FC, (c >> 14) & 0x3FC
+            const unsigned char* srgbB = reinterpret_cast<const unsigned char*>(srgb);
+            const F3 albedo = f3(*reinterpret_cast<const float*>(srgbB + ((gc << 2) & 0x3FCu)), *reinterpret_cast<const float*>(srgbB + ((gc >> 6) & 0x3FCu)),
+                                 *reinterpret_cast<const float*>(srgbB + ((gc >> 14) & 0x3FCu)));
             float ba, bb;
             {
                 // bordered coordinates: x in [0.5, W + 0.5] (NdotV is saturated), y clamped likewise (roughness is not)
