@@ -120,23 +120,42 @@ struct HzbTail {
     uint32_t SW, SH, first_mip, levels;
     float* dst[kTailMaxLevels];
     uint32_t W[kTailMaxLevels], H[kTailMaxLevels];
+    uint32_t magic[kTailMaxLevels]; // i / W[l] == __umulhi(i, magic[l]) for i < 16384 (magic = 2^32 / W + 1)
 };
+
+template <uint32_t TRIPS>
+__device__ __forceinline__ void tail_first_level(const HzbTail& p, float* bufA)
+{
+    const uint32_t tid = threadIdx.x, W = p.W[0], n = W * p.H[0];
+    float t[TRIPS][4];
+#pragma unroll
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t i = min(tid + k * 1024u, n - 1u); // clamped into the level: no branch separates the loads
+        const uint32_t y = W == 1u ? i : __umulhi(i, p.magic[0]), x = i - y * W;
+        const uint32_t x0 = min(2u * x, p.SW - 1u), x1 = min(2u * x + 1u, p.SW - 1u);
+        const uint32_t y0 = min(2u * y, p.SH - 1u) * p.SW, y1 = min(2u * y + 1u, p.SH - 1u) * p.SW;
+        t[k][0] = p.src[y0 + x0]; t[k][1] = p.src[y0 + x1];
+        t[k][2] = p.src[y1 + x0]; t[k][3] = p.src[y1 + x1];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t i = tid + k * 1024u;
+        if (i < n) {
+            const float v = min4(t[k][0], t[k][1], t[k][2], t[k][3]);
+            bufA[i] = v;
+            p.dst[0][i] = v;
+        }
+    }
+}
 
 __global__ __launch_bounds__(1024) void hzb_tail_kernel(HzbTail p)
 {
     __shared__ float bufA[kTailTexels], bufB[kTailTexels / 2];
     const uint32_t tid = threadIdx.x;
-    {   // first level of the tail: a first-of-dispatch level by construction (first_mip % 4 == 0), parent in global memory
-        const uint32_t W = p.W[0], H = p.H[0];
-        for (uint32_t i = tid; i < W * H; i += 1024u) {
-            const uint32_t y = i / W, x = i - y * W;
-            const uint32_t x0 = min(2u * x, p.SW - 1u), x1 = min(2u * x + 1u, p.SW - 1u);
-            const uint32_t y0 = min(2u * y, p.SH - 1u), y1 = min(2u * y + 1u, p.SH - 1u);
-            const float v = min4(p.src[(size_t)y0 * p.SW + x0], p.src[(size_t)y0 * p.SW + x1], p.src[(size_t)y1 * p.SW + x0], p.src[(size_t)y1 * p.SW + x1]);
-            bufA[i] = v;
-            p.dst[0][i] = v;
-        }
-    }
+    // first level of the tail: a first-of-dispatch level by construction (first_mip % 4 == 0), parent in global memory.
+    // Every load of the thread is issued before the first reduction: one memory latency (8 or 16 texels x 4 taps).
+    if (p.W[0] * p.H[0] <= kTailTexels / 2u) tail_first_level<kTailTexels / 2048u>(p, bufA);
+    else tail_first_level<kTailTexels / 1024u>(p, bufA);
     __syncthreads();
     for (uint32_t l = 1; l < p.levels; ++l) { // uniform
         const float* par = (l & 1u) ? bufA : bufB;
@@ -145,8 +164,9 @@ __global__ __launch_bounds__(1024) void hzb_tail_kernel(HzbTail p)
         const uint32_t m = p.first_mip + l;
         const bool first = (m & 3u) == 0u;                     // first level of a reference dispatch: clamped reads
         const float fill = ((m - 1u) & 3u) == 0u ? 1.0f : 0.0f; // what an out-of-range parent lane holds otherwise
+        const uint32_t mg = p.magic[l];
         for (uint32_t i = tid; i < W * H; i += 1024u) {
-            const uint32_t y = i / W, x = i - y * W;
+            const uint32_t y = W == 1u ? i : __umulhi(i, mg), x = i - y * W;
             float v;
             if (first) {
                 const uint32_t x0 = min(2u * x, PW - 1u), x1 = min(2u * x + 1u, PW - 1u);
@@ -190,6 +210,7 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
                 t.dst[k] = hzb + mips[mip + k].offset;
                 t.W[k] = mips[mip + k].width;
                 t.H[k] = mips[mip + k].height;
+                t.magic[k] = t.W[k] > 1u ? (uint32_t)((1ull << 32) / t.W[k] + 1ull) : 0u; // W == 1: y = i (handled in the kernel)
             }
             hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(1024), 0, ctx->stream, t);
             UR_HIP_TRY(hipGetLastError());
