@@ -1,19 +1,22 @@
-// DeferredLighting (GGX + IBL) and SkyAtmosphere for gfx950, as one per-pixel compute kernel with three modes.
+// DeferredLighting (GGX + IBL) and SkyAtmosphere for gfx950: per-pixel compute kernels with three modes (lighting, sky, fused).
 //
 // Reference: Shaders/DeferredLighting.hlsl:35-94 + Shaders/PBRCommon.hlsl:1-48 (fullscreen-triangle pixel shader,
 // additive ONE/ONE blend into RGBA16F, Source/Render/DeferredRenderer.cpp:1219-1255,1997-2005) and
 // Shaders/SkyAtmosphere.hlsl:40-101 (inside-out sphere, depth GREATER_EQUAL, no blend, DeferredRenderer.cpp:1263-1296).
 //
-// There is no rasteriser and no texture unit here. One lane shades one pixel; a wave64 covers a TILE_W x TILE_H pixel
-// tile so that the G-buffer loads are 8 bytes per lane over contiguous row segments and the shadow / cube / LUT gathers
-// of neighbouring lanes land on neighbouring texels. The PCF, the trilinear cube lookups and the BRDF LUT are filtered
-// in ALU from plain loads (texels fetched as whole 8-byte half4s and fed to mixed-precision FMAs).
-// Every per-launch uniform the HLSL recomputes per pixel (light vector in view space, reciprocals, the camera-ray ->
-// shadow-clip matrix, sky densities) is folded on the host into LightingParams: gfx950 has no scalar fp32 ALU, so
-// uniform math would otherwise run on the VALU for all 64 lanes. The view matrix is rigid (XMMatrixLookToLH,
-// Scene/Camera.cpp:23-31), so the world-space IBL vectors are the view-space ones rotated by ViewInverse.
-// The kernel is VALU/HBM co-limited: the instruction count per pixel is the budget that matters.
-// Tolerance against the oracle: max(1e-3, 1 ulp fp16) per channel; fp32 math, one RTE to fp16.
+// There is no rasteriser and no texture unit here. One lane shades one pixel; a wave64 covers a 16 x 4 pixel tile so that
+// the G-buffer rows are contiguous 128-byte segments and the shadow / cube gathers of neighbouring lanes land on
+// neighbouring texels. The PCF, the trilinear cube lookups and the BRDF LUT are filtered in ALU.
+//
+// Two kernels share that arithmetic:
+//   * lighting_stream_kernel (second half of this file, the default): persistent workgroups, G-buffer tiles prefetched into
+//     LDS by DMA, side tables in LDS, work claimed from an LDS counter, instruction selection tuned to gfx950's VALU issue
+//     rules (DESIGN.md section 3.3 has the measurements behind every choice);
+//   * lighting_kernel (first half): one workgroup per 64 x 4 pixels, plain loads; sky-only launches and every
+//     configuration the streaming kernel declines (launch_lighting() at the end decides per launch, never per row).
+// Every per-launch uniform the HLSL recomputes per pixel is folded on the host: gfx950 has no scalar fp32 ALU. The view
+// matrix is rigid (XMMatrixLookToLH, Scene/Camera.cpp:23-31), so world-space vectors are view-space ones rotated by
+// ViewInverse. Tolerance against the oracle: max(1e-3, 1 ulp fp16) per channel; fp32 math, one RTE to fp16.
 
 #include "ur_internal.h"
 
