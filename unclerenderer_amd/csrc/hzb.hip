@@ -17,10 +17,10 @@ namespace {
 
 struct HzbDispatch {
     const float* src;
-    float* dst[4];
+    float* dst[5];
     uint32_t SW, SH;
-    uint32_t W[4], H[4];
-    uint32_t mips;
+    uint32_t W[5], H[5];
+    uint32_t mips; // 1..4 as the reference dispatches; 5 = also the first level of the NEXT reference dispatch (see below)
     uint32_t vec4_ok; // SW % 4 == 0 and src 16-byte aligned
     uint32_t pair_ok; // W[0] even and dst[0] 8-byte aligned
 };
@@ -30,6 +30,7 @@ __device__ __forceinline__ float min4(float a, float b, float c, float d) { retu
 __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
 {
     __shared__ float sh2[4][16];
+    __shared__ float sh3[2][8];
 
     const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
     const uint32_t x1 = blockIdx.x * 32u + tx, y1 = blockIdx.y * 8u + ty; // coords in mip k+1 (== 4x4 source block index)
@@ -102,7 +103,23 @@ __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
         const uint32_t x3 = x1 >> 2, y3 = y1 >> 2;
         if (x3 < p.W[3] && y3 < p.H[3]) {
             const uint32_t cx = tx >> 1, cy = ty >> 1;
-            p.dst[3][(size_t)y3 * p.W[3] + x3] = min4(sh2[cy][cx], sh2[cy][cx + 1], sh2[cy + 1][cx], sh2[cy + 1][cx + 1]);
+            const float v3 = min4(sh2[cy][cx], sh2[cy][cx + 1], sh2[cy + 1][cx], sh2[cy + 1][cx + 1]);
+            p.dst[3][(size_t)y3 * p.W[3] + x3] = v3;
+            sh3[ty >> 2][tx >> 2] = v3;
+        }
+    }
+    if (p.mips < 5u) return; // uniform
+    __syncthreads();
+
+    // ---- mip k+4 = the FIRST level of the reference's next dispatch, produced here so that the single-workgroup tail
+    //      launch starts from a mip a quarter the size: clamped 2x2 footprints of mip k+3 (SampleDepth, :34-39). The
+    //      workgroup's 8x2 texels of mip k+3 hold every tap: a clamped coordinate of an in-range texel stays in its pair.
+    if (threadIdx.x < 4u) {
+        const uint32_t x4 = blockIdx.x * 4u + threadIdx.x, y4 = blockIdx.y;
+        if (x4 < p.W[4] && y4 < p.H[4]) {
+            const uint32_t c0 = min(2u * x4, p.W[3] - 1u) & 7u, c1 = min(2u * x4 + 1u, p.W[3] - 1u) & 7u;
+            const uint32_t r0 = min(2u * y4, p.H[3] - 1u) & 1u, r1 = min(2u * y4 + 1u, p.H[3] - 1u) & 1u;
+            p.dst[4][(size_t)y4 * p.W[4] + x4] = min4(sh3[r0][c0], sh3[r0][c1], sh3[r1][c0], sh3[r1][c1]);
         }
     }
 }
@@ -127,11 +144,16 @@ template <uint32_t TRIPS>
 __device__ __forceinline__ void tail_first_level(const HzbTail& p, float* bufA)
 {
     const uint32_t tid = threadIdx.x, W = p.W[0], n = W * p.H[0];
+    const bool first = (p.first_mip & 3u) == 0u;                     // first level of a reference dispatch: clamped reads
+    const float fill = ((p.first_mip - 1u) & 3u) == 0u ? 1.0f : 0.0f; // otherwise: what an out-of-range parent lane holds
     float t[TRIPS][4];
+    bool in1[TRIPS], in2[TRIPS];
 #pragma unroll
     for (uint32_t k = 0; k < TRIPS; ++k) {
         const uint32_t i = min(tid + k * 1024u, n - 1u); // clamped into the level: no branch separates the loads
         const uint32_t y = W == 1u ? i : __umulhi(i, p.magic[0]), x = i - y * W;
+        in1[k] = first || 2u * x + 1u < p.SW;
+        in2[k] = first || 2u * y + 1u < p.SH;
         const uint32_t x0 = min(2u * x, p.SW - 1u), x1 = min(2u * x + 1u, p.SW - 1u);
         const uint32_t y0 = min(2u * y, p.SH - 1u) * p.SW, y1 = min(2u * y + 1u, p.SH - 1u) * p.SW;
         t[k][0] = p.src[y0 + x0]; t[k][1] = p.src[y0 + x1];
@@ -141,7 +163,7 @@ __device__ __forceinline__ void tail_first_level(const HzbTail& p, float* bufA)
     for (uint32_t k = 0; k < TRIPS; ++k) {
         const uint32_t i = tid + k * 1024u;
         if (i < n) {
-            const float v = min4(t[k][0], t[k][1], t[k][2], t[k][3]);
+            const float v = min4(t[k][0], in1[k] ? t[k][1] : fill, in2[k] ? t[k][2] : fill, (in1[k] && in2[k]) ? t[k][3] : fill);
             bufA[i] = v;
             p.dst[0][i] = v;
         }
@@ -152,8 +174,8 @@ __global__ __launch_bounds__(1024) void hzb_tail_kernel(HzbTail p)
 {
     __shared__ float bufA[kTailTexels], bufB[kTailTexels / 2];
     const uint32_t tid = threadIdx.x;
-    // first level of the tail: a first-of-dispatch level by construction (first_mip % 4 == 0), parent in global memory.
-    // Every load of the thread is issued before the first reduction: one memory latency (8 or 16 texels x 4 taps).
+    // first level of the tail: parent in global memory. Every load of the thread is issued before the first reduction:
+    // one memory latency (8 or 16 texels x 4 taps).
     if (p.W[0] * p.H[0] <= kTailTexels / 2u) tail_first_level<kTailTexels / 2048u>(p, bufA);
     else tail_first_level<kTailTexels / 1024u>(p, bufA);
     __syncthreads();
@@ -216,7 +238,10 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
             UR_HIP_TRY(hipGetLastError());
             break;
         }
-        const uint32_t n = (mip_count - mip) < 4u ? (mip_count - mip) : 4u;
+        uint32_t n = (mip_count - mip) < 4u ? (mip_count - mip) : 4u;
+        // the first launch also produces mip 4 when a tail launch follows: the tail then starts from 1/4 of the texels
+        // (a single workgroup reads ~25 GB/s: 130 KB of mip 3 at 4K would be 5 us on its own)
+        if (mip == 0 && mip_count > 4u && (uint64_t)mips[4].width * mips[4].height <= kTailTexels) n = 5u;
         HzbDispatch d{};
         if (mip == 0) {
             d.src = depth;
@@ -227,7 +252,7 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
             d.SW = mips[mip - 1].width;
             d.SH = mips[mip - 1].height;
         }
-        for (uint32_t k = 0; k < 4; ++k) {
+        for (uint32_t k = 0; k < 5; ++k) {
             if (k < n) {
                 d.dst[k] = hzb + mips[mip + k].offset;
                 d.W[k] = mips[mip + k].width;
