@@ -293,6 +293,43 @@ def test_lighting_shadow_border_and_outside(hotpath, oracle):
     assert fragile.mean() < 0.05
 
 
+def test_streaming_and_per_tile_kernels_agree(hotpath, tmp_path):
+    """The two lighting kernels are independent implementations of the same pass (the per-tile one serves sky-only launches
+    and the configurations the streaming kernel declines): on the same inputs they agree within the HDR tolerance.
+    The per-tile kernel runs in a child process (UR_LIGHTING_STREAM is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    w, h = 320, 180
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=33, mode="scene")
+    tables = _device_tables(hotpath, shadow, env, lut)
+    out = to_device(g.hdr)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, out, w, h)
+    torch.cuda.synchronize()
+    stream_bits = out.cpu().numpy().view(np.uint16)
+    child = tmp_path / "per_tile.npy"
+    code = (
+        "import numpy as np, torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.test_gpu_parity import _lighting_inputs, _device_tables\n"
+        "from unclerenderer_amd.hotpath import HotPath, to_device\n"
+        "hp = HotPath(0)\n"
+        "fc, g, shadow, env, lut = _lighting_inputs('sponza', %d, %d, seed=33, mode='scene')\n"
+        "tables = _device_tables(hp, shadow, env, lut)\n"
+        "out = to_device(g.hdr)\n"
+        "hp.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, out, %d, %d)\n"
+        "torch.cuda.synchronize()\n"
+        "np.save(%r, out.cpu().numpy().view(np.uint16))\n"
+    ) % (str(__import__("pathlib").Path(__file__).resolve().parent.parent), w, h, w, h, str(child))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UR_LIGHTING_STREAM="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tile_bits = np.load(child)
+    nbad, worst, _ = hdr_mismatch(stream_bits, tile_bits)
+    assert nbad <= 8, f"{nbad} channel values differ beyond tolerance between the two kernels (worst excess {worst})"
+
+
 def test_row_bands_equal_whole_frame(hotpath):
     """Screen-tile sharding: shading 4 bands separately gives the whole-frame result bit for bit."""
     from unclerenderer_amd.hotpath import to_device
