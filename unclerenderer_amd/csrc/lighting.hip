@@ -584,10 +584,18 @@ __device__ __forceinline__ TileSrc tile_src(P p, uint32_t lane, uint32_t maxRow)
     return s;
 }
 
+// Both DMA instructions of a tile in one statement, one M0 set-up: the instruction offset (1024) moves the global AND the
+// LDS address of the second one, so its source pointer is biased by -1024.
 __device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pixel index of the tile's first pixel*/, uint32_t lds_dst)
 {
-    dma16(s.p1 + (uint64_t)origin * 8u, lds_dst);
-    dma16(s.p2 + (uint64_t)origin * s.mul2, lds_dst + 1024u);
+    const char* g1 = s.p1 + (uint64_t)origin * 8u;
+    const char* g2 = s.p2 + (uint64_t)origin * s.mul2 - 1024;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g1), "v"(g2), "s"(lds_dst)
+                 : "memory");
 }
 
 // tile (tx, ty) -> LDS; `full` = the precomputed per-lane sources of a whole tile
