@@ -29,17 +29,38 @@ def main():
     shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
     tables = hp.make_tables(to_device(shadow), hp.stage_env_cube(env, 256, 9), 256, 9, to_device(lut))
     A, B, C, D, hdr = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), to_device(g.hdr)
-    for _ in range(3):
+    for _ in range(400):  # sustained clocks: the stamps read back are those of the last launch
         hp.deferred_lighting_sky(fc.scene, fc.sky, A, B, C, D, tables, hdr, W, H)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        hp.deferred_lighting_sky(fc.scene, fc.sky, A, B, C, D, tables, hdr, W, H)
+    e1.record()
     torch.cuda.synchronize()
+    print(f"stamped build: {e0.elapsed_time(e1) * 5.0:.1f} us per launch (includes the stamp buffer's memset)")
     L = lib.load()
     waves = 4096
-    out = (ctypes.c_ulonglong * (waves * 8))()
+    out = (ctypes.c_ulonglong * (waves * 16))()
     fn = L.ur_debug_stamps
     fn.argtypes = [ctypes.c_void_p, ctypes.c_uint]
     rc = fn(out, waves)
     assert rc == 0, rc
-    a = np.frombuffer(out, dtype=np.uint64).reshape(waves, 8).astype(np.float64)
+    raw = np.frombuffer(out, dtype=np.uint64).reshape(waves, 16)
+    a = raw.astype(np.float64)
+    a[:, 5] = (raw[:, 5] & np.uint64(0xFFFF)).astype(np.float64)
+    ticks = (raw[:, 5] >> np.uint64(16)).astype(np.float64)  # whole-kernel span of the wave in 100 MHz ticks
+    live = a[:, 7] > 0
+    mhz = 100.0 * a[live, 7].sum() / ticks[live].sum()
+    print(f"shader clock during the launch: {mhz:.0f} MHz (s_memtime against s_memrealtime)")
+    q = np.percentile(a[live, 7], [0, 50, 100])
+    print(f"per-wave whole-kernel cycles min/median/max = {q[0]:.0f} {q[1]:.0f} {q[2]:.0f}  ({q[2] / mhz:.1f} us for the slowest)")
+    q = np.percentile(a[live, 6], [0, 50, 100])
+    print(f"per-wave prologue cycles (entry -> first iteration) min/median/max = {q[0]:.0f} {q[1]:.0f} {q[2]:.0f}  ({q[1] / mhz:.2f} us median)")
+    for k, n in ((8, "table loads issued, tile walk set up"), (9, "tile DMAs issued"), (10, "tables converted and in LDS"), (11, "after the barrier"), (6, "tile DMAs landed")):
+        q = np.percentile(a[live, k], [0, 50, 100])
+        print(f"   prologue, {n:45s} min/median/max = {q[0]:.0f} {q[1]:.0f} {q[2]:.0f}")
+    t0 = a[live, 12]
+    print(f"   wave entry spread (max - min of t0, counters may differ across XCDs): {t0.max() - t0.min():.0f} cycles")
     a = a[a[:, 5] > 0]
     it = a[:, 5].sum()
     names = ["top -> gathers issued", "LDS lookups + BRDF math", "shadow filter + gather wait", "vmcnt(0) at the prefetch point", "DMA issue + cube filter + combine + store"]

@@ -563,6 +563,36 @@ __device__ __forceinline__ KParams fresh_params()
     return (KParams)k; // LightingParams is the kernel's only argument: offset 0
 }
 
+// Touch every 64-byte line of the kernarg segment with one batch of scalar loads and ONE wait. The compiler reads kernel
+// parameters lazily, a few dwords at a time with a wait after each group; at the start of a launch every group is a
+// scalar-cache miss, and the ~8 dependent misses ahead of the first tile DMA were half of the kernel's prologue
+// (in-kernel stamps, tools/stamps_lighting.py). After this batch they all hit.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg()
+{
+    static_assert(BYTES >= 12 * 64 && BYTES < 13 * 64, "one load per line, 13 lines");
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12;
+    asm volatile("s_load_dword %0, %13, 0x0\n\t"
+                 "s_load_dword %1, %13, 0x40\n\t"
+                 "s_load_dword %2, %13, 0x80\n\t"
+                 "s_load_dword %3, %13, 0xc0\n\t"
+                 "s_load_dword %4, %13, 0x100\n\t"
+                 "s_load_dword %5, %13, 0x140\n\t"
+                 "s_load_dword %6, %13, 0x180\n\t"
+                 "s_load_dword %7, %13, 0x1c0\n\t"
+                 "s_load_dword %8, %13, 0x200\n\t"
+                 "s_load_dword %9, %13, 0x240\n\t"
+                 "s_load_dword %10, %13, 0x280\n\t"
+                 "s_load_dword %11, %13, 0x2c0\n\t"
+                 "s_load_dword %12, %13, %14\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
+                   "=&s"(d10), "=&s"(d11), "=&s"(d12)
+                 : "s"(k), "n"((BYTES / 64) * 64) // the line behind the explicit arguments holds the hidden ones (grid size)
+                 : "memory");
+}
+
 // maxRow = last valid row of the tile (3 for a whole tile): the rows of a partial bottom tile re-read the last valid one
 template <int MODE, class P>
 __device__ __forceinline__ TileSrc tile_src(P p, uint32_t lane, uint32_t maxRow)
@@ -663,6 +693,12 @@ template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_kernel(LightingParams p)
 {
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the per-tile kernel");
+#ifdef UR_STAMPS
+    unsigned long long t0 = 0, r0 = 0, tL = 0, tX = 0, r1 = 0, tP1 = 0, tP2 = 0, tP3 = 0, tP4 = 0;
+    UR_STAMP(t0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
+#endif
+    warm_kernarg<sizeof(LightingParams)>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* srgb = reinterpret_cast<float*>(smem + kLdsSrgb);
     MipEntry* mipT = reinterpret_cast<MipEntry*>(smem + kLdsMip);
@@ -672,6 +708,23 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform by construction: keeps the tile walk on the scalar ALU
+    // ---- Prologue order (in-kernel stamps, tools/stamps_lighting.py): the table loads go first - the barrier below waits
+    //      for their conversion, and vector memory returns in order, so behind the tile DMAs they would wait for 64 KB of
+    //      tiles per CU -, then the wave's two static tiles, then the constants only the loop needs. One memory latency
+    //      for everything.
+    constexpr uint32_t T = 64 * WPB, kLutN = kLutE * (kLutH + 2u), kLutTrips = (kLutN + T - 1) / T;
+    uint32_t lt[kLutTrips];
+#pragma unroll
+    for (uint32_t k = 0; k < kLutTrips; ++k) {
+        const uint32_t i = min(threadIdx.x + k * T, kLutN - 1u);
+        const uint32_t by = i / kLutE, bx = i - by * kLutE;
+        const uint32_t sx = min(max(bx, 1u), kLutW) - 1u, sy = min(max(by, 1u), kLutH) - 1u; // border = clamp addressing
+        lt[k] = p.lut[sy * kLutW + sx];
+    }
+    const float sv = threadIdx.x < 256u ? p.srgb[threadIdx.x] : 0.0f;
+    half4_t ih = {};
+    const uint32_t irrE = p.irrN0 + 2u, irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
+    if (threadIdx.x < irrCount) ih = p.env[p.irrOffset0 + threadIdx.x];
     // Tile schedule: chunks of 2^cs consecutive tiles are dealt round-robin to the workgroups (chunks of 4: the per-workgroup
     // work then differs by +-3 %; with 16 the image content makes it +-9 %, with 1 the DRAM locality of a row is lost),
     // dynamically inside a workgroup: a wave takes its next tile from a counter in LDS. The SIMD's oldest-first
@@ -683,12 +736,19 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     uint32_t tile = (wave >> cs) * chunkStride + base + (wave & cmask);
     uint32_t tile1 = ((wave + WPB) >> cs) * chunkStride + base + ((wave + WPB) & cmask);
     const bool have0 = tile < p.hot.numTiles; // (a grid larger than the band: some waves have no tile at all)
-    uint32_t ty = tile / p.hot.tilesX, tx = tile - ty * p.hot.tilesX;
-    uint32_t ty1 = tile1 / p.hot.tilesX, tx1 = tile1 - ty1 * p.hot.tilesX;
+    uint32_t ty = (uint32_t)(((uint64_t)tile * p.hot.tilesXMagic) >> 32), tx = tile - ty * p.hot.tilesX; // (exact for tile < numTiles)
+    uint32_t ty1 = (uint32_t)(((uint64_t)tile1 * p.hot.tilesXMagic) >> 32), tx1 = tile1 - ty1 * p.hot.tilesX;
     const uint32_t col = lane & 15u, row = lane >> 4;
     const TileSrc src = tile_src<MODE>(&p, lane, 3u);
     const uint32_t bufBase = __builtin_amdgcn_readfirstlane(lds_address(smem + kLdsTiles + wave * (2u * kTileBytes)));
     const unsigned char* myTiles = smem + kLdsTiles + wave * (2u * kTileBytes);
+    // this lane's pixel inside a tile, as a byte offset into the HDR band (the tile origin is added per iteration)
+    const uint32_t laneHdr = (row * p.hot.W + col) * 8u;
+
+
+    UR_STAMP(tP1);
+    if (have0) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
+    UR_STAMP(tP2);
     // per-lane part of the pixel's NDC (the tile origin is added per iteration), and the few uniforms that appear as the
     // SECOND scalar operand of an FMA
     const float ndcxL = fmaf((float)col, p.invW2, 0.5f * p.invW2 - 1.0f);
@@ -703,31 +763,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     for (int k = 0; k < 3; ++k) {
         WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); shT[k] = vreg(p.hot.shT[k]); lightRGB[k] = vreg(p.hot.lightRGB[k]);
     }
-    // this lane's pixel inside a tile, as a byte offset into the HDR band (the tile origin is added per iteration)
-    const uint32_t laneHdr = (row * p.hot.W + col) * 8u;
-
-    // ---- the wave's two static tiles go in flight first: their HBM latency runs under the table staging below -------------
-    if (have0) {
-        tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
-        if (tile1 < p.hot.numTiles) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
-    }
-
-    // ---- stage the tables (once per workgroup): every load is issued before the first result is converted, so the
-    //      workgroup pays one memory latency, not one per loop trip -----------------------------------------------------
+    // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
-        constexpr uint32_t T = 64 * WPB, kLutN = kLutE * (kLutH + 2u), kLutTrips = (kLutN + T - 1) / T;
-        uint32_t lt[kLutTrips];
-#pragma unroll
-        for (uint32_t k = 0; k < kLutTrips; ++k) {
-            const uint32_t i = min(threadIdx.x + k * T, kLutN - 1u);
-            const uint32_t by = i / kLutE, bx = i - by * kLutE;
-            const uint32_t sx = min(max(bx, 1u), kLutW) - 1u, sy = min(max(by, 1u), kLutH) - 1u; // border = clamp addressing
-            lt[k] = p.lut[sy * kLutW + sx];
-        }
-        const float sv = threadIdx.x < 256u ? p.srgb[threadIdx.x] : 0.0f;
-        half4_t ih = {};
-        const uint32_t irrE = p.irrN0 + 2u, irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
-        if (threadIdx.x < irrCount) ih = p.env[p.irrOffset0 + threadIdx.x];
         if (threadIdx.x == 0) *work = 2u * WPB;
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
         if (threadIdx.x < irrCount) irrT[threadIdx.x] = float4a{(float)ih.x, (float)ih.y, (float)ih.z, 0.0f};
@@ -743,8 +780,18 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
             if (i < kLutN) lut[i] = float2{(float)(lt[k] & 0xFFFFu) * (1.0f / 65535.0f), (float)(lt[k] >> 16) * (1.0f / 65535.0f)};
         }
     }
+    UR_STAMP(tP3);
     __syncthreads();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two tile DMAs
+    UR_STAMP(tP4);
+    // The second static tile goes out behind the barrier, i.e. behind every first tile of the workgroup: the start-up burst
+    // (2 KB per wave and tile, 8 MB over the chip) that the first iteration has to wait for is halved, the other half
+    // lands under the first iteration's arithmetic. Its two DMA instructions may stay in flight here.
+    if (have0 && tile1 < p.hot.numTiles) {
+        tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     uint32_t parity = 0;
 // (macro: the statement appears in the shading path and in the all-sky path)
@@ -763,6 +810,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     } while (0)
 #ifdef UR_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0, iters = 0;
+    UR_STAMP(tL);
 #endif
     while (have0) {
         UR_STAMP(tA);
@@ -1043,8 +1091,12 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
 #undef UR_PREFETCH_POINT
 #ifdef UR_STAMPS
     if (p.stamps && lane == 0) {
-        unsigned long long* o = p.stamps + (size_t)(blockIdx.x * WPB + wave) * 8u;
-        o[0] = sum0; o[1] = sum1; o[2] = sum2; o[3] = sum3; o[4] = sum4; o[5] = iters;
+        unsigned long long* o = p.stamps + (size_t)(blockIdx.x * WPB + wave) * 16u;
+        UR_STAMP(tX);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+        o[0] = sum0; o[1] = sum1; o[2] = sum2; o[3] = sum3; o[4] = sum4; o[5] = iters | ((r1 - r0) << 16);
+        o[8] = tP1 - t0; o[9] = tP2 - t0; o[10] = tP3 - t0; o[11] = tP4 - t0; o[12] = t0;
+        o[6] = tL - t0; o[7] = tX - t0; // prologue and whole-kernel cycles of this wave; [5] >> 16 = the same span in 100 MHz ticks
     }
 #endif
 }
@@ -1087,8 +1139,8 @@ template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk is filled in here */)
 {
 #ifdef UR_STAMPS
-    if (!g_stamps) UR_HIP_TRY(hipMalloc(&g_stamps, kStampWaves * 8 * sizeof(unsigned long long)));
-    UR_HIP_TRY(hipMemsetAsync(g_stamps, 0, kStampWaves * 8 * sizeof(unsigned long long), ctx->stream));
+    if (!g_stamps) UR_HIP_TRY(hipMalloc(&g_stamps, kStampWaves * 16 * sizeof(unsigned long long)));
+    UR_HIP_TRY(hipMemsetAsync(g_stamps, 0, kStampWaves * 16 * sizeof(unsigned long long), ctx->stream));
     p.stamps = g_stamps;
 #endif
     constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
@@ -1123,12 +1175,12 @@ int launch_stream(ur_ctx* ctx, const LightingParams& p)
 } // namespace
 
 #ifdef UR_STAMPS
-// diagnostic builds only: the per-wave segment sums of the last streaming launch (8 u64 per wave)
+// diagnostic builds only: the per-wave segment sums of the last streaming launch (16 u64 per wave)
 extern "C" int ur_debug_stamps(unsigned long long* out, unsigned int waves)
 {
     if (!g_stamps || waves > kStampWaves) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -2;
-    return hipMemcpy(out, g_stamps, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+    return hipMemcpy(out, g_stamps, (size_t)waves * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 #endif
 
@@ -1249,7 +1301,7 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     // moves 16 bytes per lane: 16-byte-aligned band buffers)
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                                  reinterpret_cast<uintptr_t>(p.depth) | reinterpret_cast<uintptr_t>(p.hdr);
-    if (use_stream && mode != UR_MODE_SKY && (align_bits & 15u) == 0 && ortho_err <= 1e-5f && w % 16u == 0 && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
+    if (use_stream && mode != UR_MODE_SKY && (align_bits & 15u) == 0 && ortho_err <= 1e-5f && w % 16u == 0 && w >= 32u /* the magic of one tile per row does not fit 32 bits */ && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
         bool ok = true;
         StreamHot& h = p.hot;
         if (shadows) {
