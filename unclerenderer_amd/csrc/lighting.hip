@@ -19,6 +19,7 @@
 // ViewInverse. Tolerance against the oracle: max(1e-3, 1 ulp fp16) per channel; fp32 math, one RTE to fp16.
 
 #include "ur_internal.h"
+#include "ur_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -563,36 +564,6 @@ __device__ __forceinline__ KParams fresh_params()
     return (KParams)k; // LightingParams is the kernel's only argument: offset 0
 }
 
-// Touch every 64-byte line of the kernarg segment with one batch of scalar loads and ONE wait. The compiler reads kernel
-// parameters lazily, a few dwords at a time with a wait after each group; at the start of a launch every group is a
-// scalar-cache miss, and the ~8 dependent misses ahead of the first tile DMA were half of the kernel's prologue
-// (in-kernel stamps, tools/stamps_lighting.py). After this batch they all hit.
-template <int BYTES>
-__device__ __forceinline__ void warm_kernarg()
-{
-    static_assert(BYTES >= 12 * 64 && BYTES < 13 * 64, "one load per line, 13 lines");
-    auto k = __builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12;
-    asm volatile("s_load_dword %0, %13, 0x0\n\t"
-                 "s_load_dword %1, %13, 0x40\n\t"
-                 "s_load_dword %2, %13, 0x80\n\t"
-                 "s_load_dword %3, %13, 0xc0\n\t"
-                 "s_load_dword %4, %13, 0x100\n\t"
-                 "s_load_dword %5, %13, 0x140\n\t"
-                 "s_load_dword %6, %13, 0x180\n\t"
-                 "s_load_dword %7, %13, 0x1c0\n\t"
-                 "s_load_dword %8, %13, 0x200\n\t"
-                 "s_load_dword %9, %13, 0x240\n\t"
-                 "s_load_dword %10, %13, 0x280\n\t"
-                 "s_load_dword %11, %13, 0x2c0\n\t"
-                 "s_load_dword %12, %13, %14\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
-                   "=&s"(d10), "=&s"(d11), "=&s"(d12)
-                 : "s"(k), "n"((BYTES / 64) * 64) // the line behind the explicit arguments holds the hidden ones (grid size)
-                 : "memory");
-}
-
 // maxRow = last valid row of the tile (3 for a whole tile): the rows of a partial bottom tile re-read the last valid one
 template <int MODE, class P>
 __device__ __forceinline__ TileSrc tile_src(P p, uint32_t lane, uint32_t maxRow)
@@ -698,7 +669,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_k
     UR_STAMP(t0);
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
 #endif
-    warm_kernarg<sizeof(LightingParams)>();
+    ur::warm_kernarg<sizeof(LightingParams)>(); // (ur_device.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* srgb = reinterpret_cast<float*>(smem + kLdsSrgb);
     MipEntry* mipT = reinterpret_cast<MipEntry*>(smem + kLdsMip);

@@ -1,0 +1,57 @@
+// Device-side helpers shared by the kernels. Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ur {
+
+// Touch every 64-byte line of the kernarg segment (explicit arguments of BYTES bytes plus the hidden ones behind them)
+// with one batch of scalar loads and ONE wait. hipcc reads kernel parameters lazily, a few dwords at a time with a wait
+// after each group; at the start of a launch every new line is a scalar-cache miss, and a kernel with a dozen dependent
+// groups spends microseconds on them before its first vector load (in-kernel stamps on the lighting kernel: half of its
+// prologue). After this batch they all hit. Lines behind the last one re-read the last one.
+template <uint32_t BYTES>
+__device__ __forceinline__ void warm_kernarg()
+{
+    static_assert(BYTES < 13 * 64, "one load per line, 13 lines");
+    constexpr uint32_t kLast = (BYTES / 64u) * 64u;
+#define UR_KA_LINE(i) ((i) * 64u < kLast ? (i) * 64u : kLast)
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12;
+    if constexpr (kLast <= 3 * 64u) {
+        asm volatile("s_load_dword %0, %4, %5\n\t"
+                     "s_load_dword %1, %4, %6\n\t"
+                     "s_load_dword %2, %4, %7\n\t"
+                     "s_load_dword %3, %4, %8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3)
+                     : "s"(k), "n"(UR_KA_LINE(0)), "n"(UR_KA_LINE(1)), "n"(UR_KA_LINE(2)), "n"(UR_KA_LINE(3))
+                     : "memory");
+    } else {
+        asm volatile("s_load_dword %0, %13, %14\n\t"
+                     "s_load_dword %1, %13, %15\n\t"
+                     "s_load_dword %2, %13, %16\n\t"
+                     "s_load_dword %3, %13, %17\n\t"
+                     "s_load_dword %4, %13, %18\n\t"
+                     "s_load_dword %5, %13, %19\n\t"
+                     "s_load_dword %6, %13, %20\n\t"
+                     "s_load_dword %7, %13, %21\n\t"
+                     "s_load_dword %8, %13, %22\n\t"
+                     "s_load_dword %9, %13, %23\n\t"
+                     "s_load_dword %10, %13, %24\n\t"
+                     "s_load_dword %11, %13, %25\n\t"
+                     "s_load_dword %12, %13, %26\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
+                       "=&s"(d10), "=&s"(d11), "=&s"(d12)
+                     : "s"(k), "n"(UR_KA_LINE(0)), "n"(UR_KA_LINE(1)), "n"(UR_KA_LINE(2)), "n"(UR_KA_LINE(3)), "n"(UR_KA_LINE(4)),
+                       "n"(UR_KA_LINE(5)), "n"(UR_KA_LINE(6)), "n"(UR_KA_LINE(7)), "n"(UR_KA_LINE(8)), "n"(UR_KA_LINE(9)),
+                       "n"(UR_KA_LINE(10)), "n"(UR_KA_LINE(11)), "n"(UR_KA_LINE(12))
+                     : "memory");
+    }
+#undef UR_KA_LINE
+}
+
+} // namespace ur
