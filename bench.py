@@ -201,6 +201,13 @@ def main():
     for k in range(max(args.warmup, args.min_warmup)):
         step(k, False)
     fence()
+    # host cost of one frame's submission with an empty queue (no back-pressure): if this approaches ms_per_step the run
+    # is submission-bound and the GPU idles between passes
+    th = time.perf_counter()
+    for k in range(32):
+        step(k, False)
+    host_unthrottled_ms = (time.perf_counter() - th) / 32 * 1e3
+    fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, True)
@@ -243,6 +250,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "host_submit_ms_per_step": t_enqueued / args.steps * 1e3,
+        "host_submit_unthrottled_ms_per_step": host_unthrottled_ms,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
