@@ -647,7 +647,7 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
     asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d));
 }
 
-// WPB waves per workgroup; WPB = 10 runs two workgroups per CU (5 waves/SIMD, 96 VGPRs), the others one.
+// WPB waves per workgroup, one workgroup per CU (two of 10 waves at 96 VGPRs were tried: the loop spills).
 #ifdef UR_STAMPS
 // In-kernel stamps (diagnostic build only; cdna_hip_programming.md section 7): one statement = s_memtime + its own wait.
 #define UR_STAMP(var)                                                                        \
@@ -661,7 +661,7 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 #endif
 
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
-__global__ __launch_bounds__(64 * WPB, WPB == 10 ? 5 : 1) void lighting_stream_kernel(LightingParams p)
+__global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p)
 {
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the per-tile kernel");
 #ifdef UR_STAMPS
