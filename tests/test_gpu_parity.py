@@ -454,6 +454,14 @@ def test_tonemap_parity(hotpath, oracle):
         sh = np.array([0, 8, 16, 24], np.uint32)
         d = np.abs(((got[..., None] >> sh) & 255).astype(np.int32) - ((ref[..., None] >> sh) & 255).astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())
+        # the same pixels through the other launch forms: a band whose start is only 8-byte aligned (one pixel per lane), and
+        # an odd pixel count (pixel pairs + the last pixel on its own) - bit for bit what the whole frame gave
+        d_bits = to_device(bits)
+        for sl in (slice(1, 64), slice(0, 63), slice(5, 6)):
+            part = torch.zeros((64, 257), dtype=torch.int32, device="cuda")
+            hotpath.tonemap(d_bits[sl], part[sl], 257, sl.stop - sl.start, exposure=kw.get("exposure", 1.0), gamma=kw.get("gamma", 2.2),
+                            enable_tonemap=kw.get("enable_tonemap", True), exposure_ev=ev)
+            assert torch.equal(part[sl], out[sl]), sl
 
 
 def test_lighting_with_shipped_ibl_assets(hotpath, oracle):
@@ -510,9 +518,10 @@ def test_cull_on_shipped_scene_bounds(hotpath, oracle, scene_name, file, count):
         assert 0 < ref_cnt <= count
 
 
-@pytest.mark.parametrize("w,h", [(64, 8), (67, 13), (320, 180), (1, 1), (130, 3)])
+@pytest.mark.parametrize("w,h", [(64, 8), (67, 13), (320, 180), (1, 1), (130, 3), (513, 17), (1030, 9), (255, 8), (2, 40)])
 def test_temporal_aa_bit_exact(hotpath, oracle, w, h):
-    """Next row §8f-4: LDS-tiled 3x3 clamp + blend, whole frame and 3 uneven row bands, bit for bit."""
+    """Next row §8f-4: 3x3 clamp + blend (register strips with history, the LDS-tiled kernel without), whole frame and 3
+    uneven row bands, bit for bit."""
     from unclerenderer_amd.hotpath import to_device
     torch = _torch()
     rng = np.random.default_rng(w * 31 + h)

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--hzb", action="store_true")
     ap.add_argument("--cull", action="store_true")
     ap.add_argument("--no-light", action="store_true")
+    ap.add_argument("--post", action="store_true", help="the rows behind the path: Tonemap (12 B/pixel) and TemporalAA resolve (24 B/pixel)")
     a = ap.parse_args()
     import torch
     from unclerenderer_amd import hostmath, synth
@@ -97,6 +98,19 @@ def main():
             med, mn = time_events(torch, lambda k: hp.cull_indirect_args(c, b, hz, lay, args, None, vis, cnt), a.iters)
             med2, _ = time_events(torch, lambda k: hp.cull_indirect_args(c, b, hz, lay, args), a.iters)
             print(f"[cull] n={n}: with list median {med:.1f} us min {mn:.1f} ({n / med:.0f} M inst/s); words only {med2:.1f} us; visible {int(cnt.cpu()[0])}", flush=True)
+    if a.post:
+        for (w, h) in [(1920, 1080), (3840, 2160), (7680, 4320)]:
+            ring = 6 if w < 7680 else 3  # distinct buffer sets: the inputs of a launch are not in cache from the previous one
+            hdr = [(torch.rand((h, w, 4), device="cuda") * 4.0).to(torch.float16).view(torch.int16) for _ in range(ring)]
+            hist = [(torch.rand((h, w, 4), device="cuda") * 4.0).to(torch.float16).view(torch.int16) for _ in range(ring)]
+            out8 = [torch.zeros((h, w), dtype=torch.int32, device="cuda") for _ in range(ring)]
+            out16 = [torch.zeros((h, w, 4), dtype=torch.int16, device="cuda") for _ in range(ring)]
+            med, mn = time_events(torch, lambda k: hp.tonemap(hdr[k % ring], out8[k % ring], w, h), a.iters)
+            b = 12 * w * h
+            print(f"[tonemap] {w}x{h}: median {med:.1f} us min {mn:.1f} us {b / med / 1e3:.0f} GB/s ({100 * b / med / 1e3 / 8000:.1f}% of 8 TB/s)", flush=True)
+            med, mn = time_events(torch, lambda k: hp.temporal_aa(hdr[k % ring], hist[k % ring], out16[k % ring], 0.9, True, w, h), a.iters)
+            b = 24 * w * h
+            print(f"[taa] {w}x{h}: median {med:.1f} us min {mn:.1f} us {b / med / 1e3:.0f} GB/s ({100 * b / med / 1e3 / 8000:.1f}% of 8 TB/s)", flush=True)
 
 
 if __name__ == "__main__":

@@ -2,20 +2,23 @@
 // into that box, blended by HistoryWeight.
 //
 // Reference: Shaders/TemporalAA.hlsl:12-50 ([numthreads(8,8,1)], nine Texture2D.Load per pixel, neighbour coordinates
-// clamped to the frame), pass Source/Render/DeferredRenderer.cpp:1308-1361. Here a 256-thread workgroup resolves a
-// 64x8-pixel tile: the (64+2)x(8+2) RGBA16F neighbourhood is staged ONCE through LDS with coalesced 8-byte loads (the
-// one place on this path where neighbouring pixels reuse each other's data), each lane then reads its 3x3 windows from
-// LDS for two rows. HBM: 8 B current + 8 B history read, 8 B written per pixel (24 B/pixel; halo re-reads hit L2).
+// clamped to the frame), pass Source/Render/DeferredRenderer.cpp:1308-1361. Here a wave owns a 64-column x 8-row strip
+// and keeps it in registers (see taa_strip_kernel below): no LDS, every row access 512 contiguous aligned bytes per wave,
+// 2 KB per workgroup. HBM: 8 B current + 8 B history read, 8 B written per pixel (24 B/pixel; the two halo rows of a
+// strip are L2 hits while the neighbouring strip is in flight).
 // Built with -ffp-contract=off: min/max/clamp are exact and lerp is a + t*(b-a) in fp32 with one RTE to fp16, so the
 // output is bit-identical to the oracle.
+// History of the shape (4K, 199 MB per launch; a plain 2-reads-1-write streaming kernel of that size takes 35.3 us,
+// tools/microbench/stream_ceiling.hip): 64x8 tiles through LDS 43.8 us; 16-row strips walked four rows at a time 43.8 us
+// (a chain of five dependent memory round trips per wave: 8 us of fixed cost); 8-row strips loaded in one phase 42.5 us
+// (68 VGPRs: 7 waves/SIMD, the grid took 2.3 rounds = 3); the halo texels of a strip in ONE load, 56 VGPRs, 8 waves/SIMD,
+// two rounds: 37.0 us = 5.4 TB/s.
 
 #include "ur_internal.h"
 
 namespace {
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-
-constexpr int TW = 64, TH = 8;
 
 struct TaaParams {
     const half4_t* current; // full frame
@@ -26,55 +29,100 @@ struct TaaParams {
     uint32_t use_history;
 };
 
-__global__ __launch_bounds__(256) void taa_kernel(TaaParams p)
+// ---- a wave owns a 64-column x kStripRows strip ------------------------------------------------------------------------
+// The 3x3 box is separable: per row the horizontal min/max of (left, centre, right), then the vertical min/max of three
+// consecutive rows. Left/right come from the neighbouring lanes (DPP wave shifts, no LDS); the texels left of lane 0 and
+// right of lane 63 are fetched for all rows of the strip by one load and broadcast with v_readlane. min/max run on the
+// packed fp16 pairs (exact: no rounding, the same ordering as the fp32 compares of the reference), the clamp and the
+// lerp in fp32 as in TemporalAA.hlsl:41-49.
+constexpr int kStripRows = 8;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+struct RowMinMax { half2_t mn0, mn1, mx0, mx1; }; // (R,G) and (B,A) pairs
+
+__device__ __forceinline__ half2_t as_h2(uint32_t u) { union { uint32_t u; half2_t h; } c; c.u = u; return c.h; }
+__device__ __forceinline__ uint32_t as_u(half2_t h) { union { uint32_t u; half2_t h; } c; c.h = h; return c.u; }
+__device__ __forceinline__ half2_t pk_min(half2_t a, half2_t b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ half2_t pk_max(half2_t a, half2_t b) { return __builtin_elementwise_max(a, b); }
+
+// horizontal (left, centre, right) min/max of one row; (hl0, hl1) / (hr0, hr1) = the texel left of lane 0 / right of lane 63
+__device__ __forceinline__ RowMinMax row_minmax(u32x2_t c, uint32_t hl0, uint32_t hl1, uint32_t hr0, uint32_t hr1)
 {
-    __shared__ half4_t tile[TH + 2][TW + 2];
-    const int x0 = (int)blockIdx.x * TW, r0 = (int)blockIdx.y * TH; // tile origin: x in the frame, r inside the band
-    const int maxx = (int)p.W - 1, maxy = (int)p.H - 1;
-    if (p.use_history != 0) {
-        for (int i = (int)threadIdx.x; i < (TH + 2) * (TW + 2); i += 256) {
-            const int ty = i / (TW + 2), tx = i - ty * (TW + 2);
-            const int gx = min(max(x0 + tx - 1, 0), maxx);
-            const int gy = min(max((int)p.row0 + r0 + ty - 1, 0), maxy); // neighbour coordinates clamp to the FRAME (:38)
-            tile[ty][tx] = p.current[(size_t)gy * p.W + gx];
-        }
-        __syncthreads();
+    // wave_shr:1 (0x138): lane l reads lane l-1, lane 0 keeps `old`; wave_shl:1 (0x130): lane l reads lane l+1, lane 63 keeps `old`
+    const uint32_t l0 = __builtin_amdgcn_update_dpp(hl0, c.x, 0x138, 0xF, 0xF, false), l1 = __builtin_amdgcn_update_dpp(hl1, c.y, 0x138, 0xF, 0xF, false);
+    const uint32_t r0 = __builtin_amdgcn_update_dpp(hr0, c.x, 0x130, 0xF, 0xF, false), r1 = __builtin_amdgcn_update_dpp(hr1, c.y, 0x130, 0xF, 0xF, false);
+    RowMinMax m;
+    m.mn0 = pk_min(pk_min(as_h2(l0), as_h2(r0)), as_h2(c.x)); m.mn1 = pk_min(pk_min(as_h2(l1), as_h2(r1)), as_h2(c.y));
+    m.mx0 = pk_max(pk_max(as_h2(l0), as_h2(r0)), as_h2(c.x)); m.mx1 = pk_max(pk_max(as_h2(l1), as_h2(r1)), as_h2(c.y));
+    return m;
+}
+
+__global__ __launch_bounds__(256) void taa_strip_kernel(TaaParams p)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the four waves of a workgroup sit side by side: a workgroup touches 2 KB of contiguous bytes per row and buffer
+    // (with the waves stacked vertically - 512-byte segments - the kernel ran at 4.5 TB/s, as did the LDS-tiled one with
+    // its 64x8 tiles; a plain streaming kernel of the same byte mix reaches 5.6: tools/microbench/stream_ceiling.hip)
+    const uint32_t x0 = (blockIdx.x * 4u + wave) * 64u;
+    const uint32_t r0 = blockIdx.y * (uint32_t)kStripRows; // first row of the strip inside the band
+    if (x0 >= p.W) return;                                 // uniform per wave (no barrier in this kernel)
+    const uint32_t maxx = p.W - 1u, maxy = p.H - 1u;
+    const uint32_t px = x0 + lane, cx = min(px, maxx);                    // lanes right of the frame re-read the last column
+    // halo texels: ONE load for the whole strip - lane k holds the texel left of the strip in row k, lane 32 + k the one
+    // right of it (k < kStripRows + 2); row k's pair is broadcast from there when the row is reduced
+    const uint32_t hx = lane < 32u ? (x0 == 0u ? 0u : x0 - 1u) : min(x0 + 64u, maxx); // clamped to the frame (:38)
+    const u32x2_t* cur = reinterpret_cast<const u32x2_t*>(p.current);
+    const u32x2_t* his = reinterpret_cast<const u32x2_t*>(p.history);
+    u32x2_t* out = reinterpret_cast<u32x2_t*>(p.output);
+
+    auto frame_row = [&](int band_row) -> size_t { // band row (may be -1 or rows) -> clamped frame row offset in texels
+        const int fr = (int)p.row0 + band_row;
+        return (size_t)(uint32_t)min(max(fr, 0), (int)maxy) * p.W;
+    };
+    if (p.use_history == 0) { // UseHistory == 0: the resolve is a copy of the current frame (TemporalAA.hlsl:23-27)
+        for (uint32_t k = 0; k < min((uint32_t)kStripRows, p.rows - r0); ++k)
+            if (px <= maxx) out[(size_t)(r0 + k) * p.W + px] = cur[frame_row((int)(r0 + k)) + px];
+        return;
     }
-    const int lx = (int)(threadIdx.x & 63u), ly = (int)(threadIdx.x >> 6);
-    const int px = x0 + lx;
-    if (px > maxx) return;
+    // One load phase per wave: the strip's kStripRows + 2 current rows (with their halo texels) and kStripRows history
+    // rows are all in flight before the first is used - a wave's life is one memory round trip, the arithmetic, the
+    // stores. (Walking a taller strip group by group made every wave a chain of five dependent round trips: 8 us of
+    // fixed cost per launch at any frame size.) Later workgroups of the grid load while earlier ones compute and store.
+    u32x2_t c[kStripRows + 2], hist[kStripRows];
+    const u32x2_t halo = cur[frame_row((int)r0 - 1 + (int)min(lane & 31u, (uint32_t)kStripRows + 1u)) + hx];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int tr = ly * 2 + k;     // row inside the tile
-        const int r = r0 + tr;         // row inside the band
-        if (r >= (int)p.rows) continue;
-        const size_t band_i = (size_t)r * p.W + px;
-        if (p.use_history == 0) {
-            p.output[band_i] = p.current[(size_t)(p.row0 + r) * p.W + px];
-            continue;
-        }
-        const half4_t cur = tile[tr + 1][lx + 1];
-        float mn[3] = {(float)cur.x, (float)cur.y, (float)cur.z}, mx[3] = {mn[0], mn[1], mn[2]};
+    for (int k = 0; k < kStripRows + 2; ++k) c[k] = cur[frame_row((int)r0 + k - 1) + cx];
 #pragma unroll
-        for (int oy = 0; oy < 3; ++oy)
+    for (int k = 0; k < kStripRows; ++k) hist[k] = his[(size_t)min(r0 + (uint32_t)k, p.rows - 1u) * p.W + cx];
+    const uint32_t nrows = min((uint32_t)kStripRows, p.rows - r0);
+    auto reduce_row = [&](int k) {
+        return row_minmax(c[k], __builtin_amdgcn_readlane(halo.x, k), __builtin_amdgcn_readlane(halo.y, k),
+                          __builtin_amdgcn_readlane(halo.x, 32 + k), __builtin_amdgcn_readlane(halo.y, 32 + k));
+    };
+    RowMinMax mPrev = reduce_row(0), mCur = reduce_row(1);
 #pragma unroll
-            for (int ox = 0; ox < 3; ++ox) {
-                const half4_t s = tile[tr + oy][lx + ox];
-                mn[0] = fminf(mn[0], (float)s.x); mn[1] = fminf(mn[1], (float)s.y); mn[2] = fminf(mn[2], (float)s.z);
-                mx[0] = fmaxf(mx[0], (float)s.x); mx[1] = fmaxf(mx[1], (float)s.y); mx[2] = fmaxf(mx[2], (float)s.z);
+    for (int k = 0; k < kStripRows; ++k) {
+        const uint32_t r = r0 + (uint32_t)k;
+        const RowMinMax mNext = reduce_row(k + 2);
+        if ((uint32_t)k < nrows && px <= maxx) {
+            const half2_t mn0 = pk_min(pk_min(mPrev.mn0, mNext.mn0), mCur.mn0), mn1 = pk_min(pk_min(mPrev.mn1, mNext.mn1), mCur.mn1);
+            const half2_t mx0 = pk_max(pk_max(mPrev.mx0, mNext.mx0), mCur.mx0), mx1 = pk_max(pk_max(mPrev.mx1, mNext.mx1), mCur.mx1);
+            const half2_t c0 = as_h2(c[k + 1].x), c1 = as_h2(c[k + 1].y), h0 = as_h2(hist[k].x), h1 = as_h2(hist[k].y);
+            const float cf[3] = {(float)c0.x, (float)c0.y, (float)c1.x};
+            const float hv[3] = {(float)h0.x, (float)h0.y, (float)h1.x};
+            const float mn[3] = {(float)mn0.x, (float)mn0.y, (float)mn1.x}, mx[3] = {(float)mx0.x, (float)mx0.y, (float)mx1.x};
+            float b[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float hc = fminf(fmaxf(hv[ch], mn[ch]), mx[ch]); // clamp(History, Min, Max)
+                b[ch] = cf[ch] + p.weight * (hc - cf[ch]);            // lerp(Current, History, w)
             }
-        const half4_t h = p.history[band_i];
-        const float c[3] = {(float)cur.x, (float)cur.y, (float)cur.z};
-        const float hv[3] = {(float)h.x, (float)h.y, (float)h.z};
-        half4_t o;
-        float b[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float hc = fminf(fmaxf(hv[ch], mn[ch]), mx[ch]); // clamp(History, Min, Max)
-            b[ch] = c[ch] + p.weight * (hc - c[ch]);              // lerp(Current, History, w)
+            half2_t o0, o1;
+            o0.x = (_Float16)b[0]; o0.y = (_Float16)b[1]; o1.x = (_Float16)b[2]; o1.y = c1.y; // alpha of the current texel
+            out[(size_t)r * p.W + px] = u32x2_t{as_u(o0), as_u(o1)};
         }
-        o.x = (_Float16)b[0]; o.y = (_Float16)b[1]; o.z = (_Float16)b[2]; o.w = cur.w;
-        p.output[band_i] = o;
+        mPrev = mCur; mCur = mNext;
     }
 }
 
@@ -94,7 +142,7 @@ extern "C" int ur_temporal_aa(ur_ctx* ctx, const ur_half4* current_frame, const 
     p.weight = history_weight < 0.0f ? 0.0f : (history_weight > 1.0f ? 1.0f : history_weight);
     if (!(history_weight == history_weight)) p.weight = 0.0f; // saturate(NaN) = 0
     p.use_history = use_history ? 1u : 0u;
-    hipLaunchKernelGGL(taa_kernel, dim3((w + TW - 1) / TW, (rows + TH - 1) / TH), dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL(taa_strip_kernel, dim3((w + 255u) / 256u, (rows + kStripRows - 1u) / kStripRows), dim3(256), 0, ctx->stream, p);
     UR_HIP_TRY(hipGetLastError());
     return UR_OK;
 }

@@ -23,12 +23,10 @@ struct TonemapParams {
 __device__ __forceinline__ float pow_pos(float x, float e) { return x > 0.0f ? __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x)) : 0.0f; }
 __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f + 0.5f); }
 
-__global__ __launch_bounds__(256) void tonemap_kernel(TonemapParams p)
+// one pixel: RGBA16F -> packed R8G8B8A8 (Tonemap.hlsl:57-79)
+__device__ __forceinline__ uint32_t tonemap_pixel(const TonemapParams& p, float finalExposure, half4_t h)
 {
-    float finalExposure = p.exposure;
-    if (p.enable_auto_exposure != 0 && p.exposure_ev != nullptr) finalExposure *= __builtin_amdgcn_exp2f(p.exposure_ev[0]);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.count; i += gridDim.x * 256u) {
-        const half4_t h = p.hdr[i];
+    {   // (block kept so that the body reads like the shader's main)
         float r = (float)h.x * finalExposure, g = (float)h.y * finalExposure, b = (float)h.z * finalExposure;
         if (p.enable_tonemap != 0) { // PBRNeutralToneMapping, Tonemap.hlsl:34-55
             const float startCompression = 0.8f - 0.04f, desaturation = 0.15f;
@@ -38,16 +36,59 @@ __global__ __launch_bounds__(256) void tonemap_kernel(TonemapParams p)
             const float peak = fmaxf(r, fmaxf(g, b));
             if (!(peak < startCompression)) {
                 const float d = 1.0f - startCompression;
-                const float newPeak = 1.0f - d * d / (peak + d - startCompression);
-                const float s = newPeak / fmaxf(peak, 1e-4f);
+                // the three quotients through v_rcp_f32 (1 ulp): an IEEE divide is ~12 instructions each, which made this
+                // stream VALU-bound; the 8-bit result moves by at most the one LSB the pow already allows
+                const float newPeak = 1.0f - d * d * __builtin_amdgcn_rcpf(peak + d - startCompression);
+                const float s = newPeak * __builtin_amdgcn_rcpf(fmaxf(peak, 1e-4f));
                 r *= s; g *= s; b *= s;
-                const float gm = 1.0f - 1.0f / (desaturation * (peak - newPeak) + 1.0f);
+                const float gm = 1.0f - __builtin_amdgcn_rcpf(desaturation * (peak - newPeak) + 1.0f);
                 r = r + gm * (newPeak - r); g = g + gm * (newPeak - g); b = b + gm * (newPeak - b);
             }
         }
         r = fminf(fmaxf(r, 0.0f), 1.0f); g = fminf(fmaxf(g, 0.0f), 1.0f); b = fminf(fmaxf(b, 0.0f), 1.0f);
         r = pow_pos(r, p.inv_gamma); g = pow_pos(g, p.inv_gamma); b = pow_pos(b, p.inv_gamma);
-        p.out[i] = unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
+        return unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xFF000000u;
+    }
+}
+
+__device__ __forceinline__ float final_exposure(const TonemapParams& p)
+{
+    float e = p.exposure;
+    if (p.enable_auto_exposure != 0 && p.exposure_ev != nullptr) e *= __builtin_amdgcn_exp2f(p.exposure_ev[0]);
+    return e;
+}
+
+// any count, any alignment: one pixel per lane and trip
+__global__ __launch_bounds__(256) void tonemap_kernel(TonemapParams p)
+{
+    const float finalExposure = final_exposure(p);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < p.count; i += gridDim.x * 256u) p.out[i] = tonemap_pixel(p, finalExposure, p.hdr[i]);
+}
+
+// The streaming form (16-byte aligned buffers): a lane converts pixel PAIRS - one 16-byte load, one 8-byte store, both
+// lane-consecutive (1 KB and 512 B per wave instruction) - and a wave takes kPairTrips of them, 128 pixels apart, with
+// every load issued before the first conversion. Pixels [first, first + pairs * 2).
+constexpr uint32_t kPairTrips = 4, kPixelsPerBlock = 256u * 2u * kPairTrips;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void tonemap_pairs_kernel(TonemapParams p)
+{
+    const float finalExposure = final_exposure(p);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // pair index of trip k: ((block * 4 + wave) * kPairTrips + k) * 64 + lane
+    const uint32_t pair0 = (blockIdx.x * 4u + wave) * (kPairTrips * 64u) + lane, npairs = p.count >> 1;
+    const u32x4_t* src = reinterpret_cast<const u32x4_t*>(p.hdr);
+    u32x4_t v[kPairTrips];
+#pragma unroll
+    for (uint32_t k = 0; k < kPairTrips; ++k) v[k] = src[min(pair0 + k * 64u, npairs - 1u)];
+#pragma unroll
+    for (uint32_t k = 0; k < kPairTrips; ++k) {
+        const uint32_t pr = pair0 + k * 64u;
+        if (pr < npairs) {
+            union { u32x2_t u; half4_t h; } a, b;
+            a.u = u32x2_t{v[k].x, v[k].y}; b.u = u32x2_t{v[k].z, v[k].w};
+            reinterpret_cast<u32x2_t*>(p.out)[pr] = u32x2_t{tonemap_pixel(p, finalExposure, a.h), tonemap_pixel(p, finalExposure, b.h)};
+        }
     }
 }
 
@@ -69,7 +110,15 @@ extern "C" int ur_tonemap(ur_ctx* ctx, const ur_tonemap_constants* constants, co
     p.enable_auto_exposure = constants->EnableAutoExposure;
     p.exposure = constants->Exposure;
     p.inv_gamma = 1.0f / (constants->Gamma > 1e-3f ? constants->Gamma : 1e-3f);
-    uint32_t blocks = (uint32_t)((n + 255u) / 256u);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(hdr) & 15u) == 0u) && ((reinterpret_cast<uintptr_t>(out_rgba8) & 7u) == 0u);
+    if (aligned && n >= 2u) {
+        hipLaunchKernelGGL(tonemap_pairs_kernel, dim3((uint32_t)((n / 2u * 2u + kPixelsPerBlock - 1u) / kPixelsPerBlock)), dim3(256), 0, ctx->stream, p);
+        UR_HIP_TRY(hipGetLastError());
+        if ((n & 1u) == 0u) return UR_OK;
+        // the odd last pixel
+        p.hdr += n - 1u; p.out += n - 1u; p.count = 1u;
+    }
+    uint32_t blocks = (uint32_t)((p.count + 255u) / 256u);
     const uint32_t cap = (uint32_t)ctx->cu_count * 8u * 2u;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(tonemap_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p);
