@@ -33,7 +33,7 @@ SOURCES = [
     # packed fp32 VALU ops are not faster on gfx950 and cost v_mov traffic; the atomic optimizer would turn the one-lane LDS
     # work-counter claim into a scan + broadcast with an immediate wait
     ("lighting.hip", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]),
-    ("tonemap.hip", []),
+    ("tonemap.hip", EXACT),
     ("taa.hip", EXACT),
     ("scene.cpp", ["-x", "hip"] + EXACT),
     ("dds.cpp", ["-x", "hip"] + EXACT),

@@ -4,6 +4,8 @@
 // Khronos PBR-neutral curve, saturate, gamma) writing the R8G8B8A8_UNORM back buffer, pass
 // Source/Render/DeferredRenderer.cpp:1449-1513. One lane converts one pixel: 8-byte load, 4-byte store (12 B/pixel),
 // a pure HBM stream. Run on a rank's band BEFORE the multi-GPU gather it halves the xGMI payload (8 -> 4 B/pixel).
+// Built with -ffp-contract=off and explicit fmaf: the pixel-pair form, the one-pixel form and a band of either give the
+// same bits for the same pixel (the oracle comparison allows one LSB: exp2/log2 vs powf, v_rcp vs divide).
 
 #include "ur_internal.h"
 
@@ -21,7 +23,7 @@ struct TonemapParams {
 };
 
 __device__ __forceinline__ float pow_pos(float x, float e) { return x > 0.0f ? __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x)) : 0.0f; }
-__device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f + 0.5f); }
+__device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)fmaf(fminf(fmaxf(x, 0.0f), 1.0f), 255.0f, 0.5f); }
 
 // one pixel: RGBA16F -> packed R8G8B8A8 (Tonemap.hlsl:57-79)
 __device__ __forceinline__ uint32_t tonemap_pixel(const TonemapParams& p, float finalExposure, half4_t h)
@@ -31,18 +33,18 @@ __device__ __forceinline__ uint32_t tonemap_pixel(const TonemapParams& p, float 
         if (p.enable_tonemap != 0) { // PBRNeutralToneMapping, Tonemap.hlsl:34-55
             const float startCompression = 0.8f - 0.04f, desaturation = 0.15f;
             const float x = fminf(r, fminf(g, b));
-            const float offset = x < 0.08f ? x - 6.25f * x * x : 0.04f;
+            const float offset = x < 0.08f ? fmaf(-6.25f * x, x, x) : 0.04f;
             r -= offset; g -= offset; b -= offset;
             const float peak = fmaxf(r, fmaxf(g, b));
             if (!(peak < startCompression)) {
                 const float d = 1.0f - startCompression;
                 // the three quotients through v_rcp_f32 (1 ulp): an IEEE divide is ~12 instructions each, which made this
                 // stream VALU-bound; the 8-bit result moves by at most the one LSB the pow already allows
-                const float newPeak = 1.0f - d * d * __builtin_amdgcn_rcpf(peak + d - startCompression);
+                const float newPeak = fmaf(-(d * d), __builtin_amdgcn_rcpf(peak + d - startCompression), 1.0f);
                 const float s = newPeak * __builtin_amdgcn_rcpf(fmaxf(peak, 1e-4f));
                 r *= s; g *= s; b *= s;
-                const float gm = 1.0f - __builtin_amdgcn_rcpf(desaturation * (peak - newPeak) + 1.0f);
-                r = r + gm * (newPeak - r); g = g + gm * (newPeak - g); b = b + gm * (newPeak - b);
+                const float gm = 1.0f - __builtin_amdgcn_rcpf(fmaf(desaturation, peak - newPeak, 1.0f));
+                r = fmaf(gm, newPeak - r, r); g = fmaf(gm, newPeak - g, g); b = fmaf(gm, newPeak - b, b);
             }
         }
         r = fminf(fmaxf(r, 0.0f), 1.0f); g = fminf(fmaxf(g, 0.0f), 1.0f); b = fminf(fmaxf(b, 0.0f), 1.0f);
@@ -66,11 +68,14 @@ __global__ __launch_bounds__(256) void tonemap_kernel(TonemapParams p)
 }
 
 // The streaming form (16-byte aligned buffers): a lane converts pixel PAIRS - one 16-byte load, one 8-byte store, both
-// lane-consecutive (1 KB and 512 B per wave instruction) - and a wave takes kPairTrips of them, 128 pixels apart, with
-// every load issued before the first conversion. Pixels [first, first + pairs * 2).
-constexpr uint32_t kPairTrips = 4, kPixelsPerBlock = 256u * 2u * kPairTrips;
+// lane-consecutive (1 KB and 512 B per wave instruction) - and a wave takes TRIPS of them, 128 pixels apart, with every
+// load issued before the first conversion. Pixels [0, count & ~1). Measured (4K / 8K, us): TRIPS 1: 20.5 / 75.2,
+// 2: 21.0 / 72.9, 4: 22.4 / 72.3 - short waves keep loading and converting waves mixed on a CU, long ones save launches
+// of waves once the grid is many rounds deep; a plain 2:1 streaming kernel of the 4K size takes 19.2 us
+// (tools/microbench/stream_ceiling.hip).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <uint32_t kPairTrips>
 __global__ __launch_bounds__(256) void tonemap_pairs_kernel(TonemapParams p)
 {
     const float finalExposure = final_exposure(p);
@@ -112,7 +117,8 @@ extern "C" int ur_tonemap(ur_ctx* ctx, const ur_tonemap_constants* constants, co
     p.inv_gamma = 1.0f / (constants->Gamma > 1e-3f ? constants->Gamma : 1e-3f);
     const bool aligned = ((reinterpret_cast<uintptr_t>(hdr) & 15u) == 0u) && ((reinterpret_cast<uintptr_t>(out_rgba8) & 7u) == 0u);
     if (aligned && n >= 2u) {
-        hipLaunchKernelGGL(tonemap_pairs_kernel, dim3((uint32_t)((n / 2u * 2u + kPixelsPerBlock - 1u) / kPixelsPerBlock)), dim3(256), 0, ctx->stream, p);
+        if (n < (24u << 20)) hipLaunchKernelGGL(tonemap_pairs_kernel<1>, dim3((uint32_t)((n / 2u * 2u + 511u) / 512u)), dim3(256), 0, ctx->stream, p);
+        else hipLaunchKernelGGL(tonemap_pairs_kernel<2>, dim3((uint32_t)((n / 2u * 2u + 1023u) / 1024u)), dim3(256), 0, ctx->stream, p);
         UR_HIP_TRY(hipGetLastError());
         if ((n & 1u) == 0u) return UR_OK;
         // the odd last pixel
