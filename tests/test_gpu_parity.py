@@ -520,7 +520,7 @@ def test_cull_on_shipped_scene_bounds(hotpath, oracle, scene_name, file, count):
 
 @pytest.mark.parametrize("w,h", [(64, 8), (67, 13), (320, 180), (1, 1), (130, 3), (513, 17), (1030, 9), (255, 8), (2, 40)])
 def test_temporal_aa_bit_exact(hotpath, oracle, w, h):
-    """Next row §8f-4: 3x3 clamp + blend (register strips with history, the LDS-tiled kernel without), whole frame and 3
+    """Next row §8f-4: 3x3 clamp + blend (64-column x 8-row register strips; without history a copy), whole frame and 3
     uneven row bands, bit for bit."""
     from unclerenderer_amd.hotpath import to_device
     torch = _torch()
