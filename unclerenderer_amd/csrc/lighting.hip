@@ -1266,13 +1266,17 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     // ---- streaming kernel when the band is a whole number of 16-pixel tile columns; the per-tile kernel otherwise -----------
     static const int use_stream = env_int("UR_LIGHTING_STREAM", 1);
     bool streamed = false;
+    // (the streaming kernel addresses the staged cube in fp32: texel indices must stay below 2^24, i.e. base sizes up to 1024)
+    uint64_t env_texels = 0;
+    if (mode != UR_MODE_SKY)
+        for (uint32_t m = 0; m < p.envMips; ++m) { const uint64_t e = (uint64_t)std::max(1u, p.envBase >> m) + 2u; env_texels += 6u * e * e; }
     const uint64_t n_tiles = (uint64_t)(w / 16u) * ((rows + 3u) / 4u);
     const uint64_t magic_err = w >= 16u ? ((1ull << 32) / (w / 16u) + 1ull) * (w / 16u) - (1ull << 32) : 0;
     // (the streaming kernel takes its dot products in world space: the rotation must be orthonormal to rounding; its tile DMA
     // moves 16 bytes per lane: 16-byte-aligned band buffers)
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                                  reinterpret_cast<uintptr_t>(p.depth) | reinterpret_cast<uintptr_t>(p.hdr);
-    if (use_stream && mode != UR_MODE_SKY && (align_bits & 15u) == 0 && ortho_err <= 1e-5f && w % 16u == 0 && w >= 32u /* the magic of one tile per row does not fit 32 bits */ && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f) {
+    if (use_stream && mode != UR_MODE_SKY && (align_bits & 15u) == 0 && ortho_err <= 1e-5f && w % 16u == 0 && w >= 32u /* the magic of one tile per row does not fit 32 bits */ && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f && env_texels < (1ull << 24)) {
         bool ok = true;
         StreamHot& h = p.hot;
         if (shadows) {
