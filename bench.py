@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--async-compute", action="store_true",
                     help="put the visibility passes on the graph's async-compute stream. Off by default: the streaming lighting kernel "
                          "keeps every CU's register file full, so the passes no longer run beside it (measured: same frame time)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one frame per buffer set in a HIP graph (torch.cuda.CUDAGraph) and replay it; frames that carry the "
+                         "Lighting event pair are still submitted eagerly")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each frame's HDR all-gather before the next frame starts")
     ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +90,9 @@ def main():
         raise SystemExit(f"height {H} not divisible by {N} ranks")
     band = H // N
     row0 = rank * band
+    if args.graph:
+        # stream capture is not allowed on the legacy default stream: the whole run uses one explicit stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
     hp = HotPath(local_rank)
     dev = local_rank
 
@@ -178,7 +184,10 @@ def main():
         if s.get("gather") is not None:  # this buffer set's previous all-gather must have finished before it is shaded into again
             s["gather"].wait()
             s["gather"] = None
-        frame.render(s["res"], cull_consts, fc.scene, fc.sky, timed_flags if (timed and k % light_every == 0) else flags)
+        if args.graph and "graph" in s and not (timed and k % light_every == 0):
+            s["graph"].replay()
+        else:
+            frame.render(s["res"], cull_consts, fc.scene, fc.sky, timed_flags if (timed and k % light_every == 0) else flags)
         if N > 1:
             # RCCL all-gather of the bands on the communication stream, behind this frame's passes; the next frames (other
             # buffer sets of the ring) are shaded while it runs — frames in flight, as the reference keeps three
@@ -198,6 +207,15 @@ def main():
 
     # The chip needs ~10-20 ms of continuous work to reach its sustained clock and a 4K frame is ~0.1 ms: never fewer than
     # `--min-warmup` untimed frames, whatever W says (they are warm-up steps like the others; K timed steps follow).
+    if args.graph:
+        for k in range(2 * ring):  # everything lazy (workspace, function attributes) happens before the capture
+            step(k, False)
+        fence()
+        for s in sets:
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=torch.cuda.current_stream()):
+                frame.render(s["res"], cull_consts, fc.scene, fc.sky, flags)
+            s["graph"] = g_
     for k in range(max(args.warmup, args.min_warmup)):
         step(k, False)
     fence()
@@ -262,7 +280,7 @@ def main():
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
-            "async_compute": args.async_compute, "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
+            "async_compute": args.async_compute, "hip_graph": bool(args.graph), "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
         },
         "roofline": {
             "kernel": "lighting_stream_kernel<FUSED>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
