@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--async-compute", action="store_true",
                     help="put the visibility passes on the graph's async-compute stream. Off by default: the streaming lighting kernel "
                          "keeps every CU's register file full, so the passes no longer run beside it (measured: same frame time)")
+    ap.add_argument("--separate-hzb-tail", action="store_true",
+                    help="launch the single-workgroup tail of Build HZB on its own (three visibility launches per frame) instead of "
+                         "letting it ride along with the Lighting launch as an extra workgroup")
     ap.add_argument("--graph", action="store_true",
                     help="capture one frame per buffer set in a HIP graph (torch.cuda.CUDAGraph) and replay it; frames that carry the "
                          "Lighting event pair are still submitted eagerly")
@@ -164,6 +167,8 @@ def main():
     frame = Frame(hp, frames_in_flight=3, rank=rank, world_size=N)
     hzb = torch.zeros(lay.total, dtype=torch.float32, device=f"cuda:{dev}")
     flags = urlib.UR_FRAME_DEFAULT | urlib.UR_FRAME_FUSE_LIGHTING_SKY
+    if not args.separate_hzb_tail:
+        flags |= urlib.UR_FRAME_HZB_TAIL_WITH_LIGHTING  # (ignored with --async-compute)
     if args.async_compute:
         # visibility passes on the async-compute stream; joined once before the timed region closes (nothing on the
         # main stream consumes their outputs or overwrites their inputs inside the loop)
@@ -280,7 +285,7 @@ def main():
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
-            "async_compute": args.async_compute, "hip_graph": bool(args.graph), "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
+            "async_compute": args.async_compute, "hip_graph": bool(args.graph), "hzb_tail": "separate launch" if (args.separate_hzb_tail or args.async_compute) else "extra workgroup of the Lighting launch", "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
         },
         "roofline": {
             "kernel": "lighting_stream_kernel<FUSED>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -50,6 +50,7 @@ typedef struct ur_frame_resources {
 #define UR_FRAME_ASYNC_NO_JOIN 0x400u /* with ASYNC_COMPUTE: do not end the frame with a main<-async join; the caller calls ur_frame_join_async() */
 #define UR_FRAME_TONEMAP 0x800u /* add the Tonemap pass after Sky (Exposure 0.9, Gamma 2.2, PBR-neutral curve) */
 #define UR_FRAME_TIME_LIGHTING 0x1000u /* bracket the Lighting pass with a HIP event pair on its stream; read with ur_frame_lighting_times() */
+#define UR_FRAME_HZB_TAIL_WITH_LIGHTING 0x2000u /* the single-workgroup tail of Build HZB rides along with the Lighting launch (ur_defer_hzb_tail); ignored with ASYNC_COMPUTE. The Build HZB pass then ends before the chain is complete; the frame is complete when ur_frame_render's launches are */
 #define UR_FRAME_DEFAULT (UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY)
 
 ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size);

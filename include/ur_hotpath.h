@@ -125,6 +125,16 @@ ur_ctx* ur_create(int device, void* stream);
 void ur_destroy(ur_ctx* ctx);
 /* Pre-size the compaction workspace so later calls allocate nothing (graph-capture safe). */
 int ur_reserve(ur_ctx* ctx, uint32_t max_instances);
+/* Launch scheduling across passes (no counterpart in the reference, whose passes are separate D3D12 dispatches;
+ * DeferredRenderer.cpp:1046-1207 builds the HZB, :1997-2005 lights). The last launch of ur_build_hzb is ONE workgroup
+ * (the mips that fit LDS): ~5 us during which the rest of the chip idles. With ur_defer_hzb_tail(ctx, 1) that workgroup
+ * is held back and rides along with the next ur_deferred_lighting / ur_deferred_lighting_sky launch on the same context
+ * as an extra workgroup (when that launch uses the streaming kernel; the HZB is complete when that launch is). Anything
+ * else that reads or rewrites the HZB through this context (ur_cull_indirect_args*, ur_build_hzb), ur_flush(),
+ * ur_defer_hzb_tail(ctx, 0) and ur_destroy() launch a held-back tail on its own first. A caller that reads the HZB by
+ * other means (its own kernels, a copy) calls ur_flush() before. Off by default. */
+int ur_defer_hzb_tail(ur_ctx* ctx, int enable);
+int ur_flush(ur_ctx* ctx);
 const char* ur_last_error(void);
 const char* ur_version(void);
 

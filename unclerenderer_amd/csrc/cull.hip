@@ -215,6 +215,10 @@ namespace ur {
 int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb, const ur_mip_desc* mips,
                 void* indirect_args, uint32_t* stats2, uint32_t* visible_idx, uint32_t* visible_count, uint32_t index_base)
 {
+    {
+        const int rc = flush_hzb_tail(ctx); // the cull reads the whole chain
+        if (rc != UR_OK) return rc;
+    }
     CullParams P{};
     static_assert(sizeof(float4) * 6 + sizeof(float) * 16 + 6 * 4 == UR_CULL_CONSTANT_DWORDS * 4, "46 dwords");
     std::memcpy(&P, constants, UR_CULL_CONSTANT_DWORDS * 4);

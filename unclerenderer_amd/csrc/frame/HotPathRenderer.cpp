@@ -298,7 +298,15 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     O.bBarrierLogs = (flags & UR_FRAME_BARRIER_LOGS) != 0;
     f->Cmd.SetJoinAsyncAtEnd((flags & UR_FRAME_ASYNC_NO_JOIN) == 0);
     f->Cmd.BeginFrame();
-    return f->Renderer.RenderFrame(f->Cmd, R, K, O);
+    // Launch scheduling across two passes (include/ur_hotpath.h, ur_defer_hzb_tail): only when both run on the main stream
+    const bool tail_with_lighting = (flags & UR_FRAME_HZB_TAIL_WITH_LIGHTING) != 0 && !O.bAsyncCompute;
+    if (tail_with_lighting) (void)ur_defer_hzb_tail(f->Cmd.GetContext(), 1);
+    const int rc = f->Renderer.RenderFrame(f->Cmd, R, K, O);
+    if (tail_with_lighting) {
+        const int rc2 = ur_defer_hzb_tail(f->Cmd.GetContext(), 0); // launches the tail on its own if no Lighting launch took it
+        return rc != UR_OK ? rc : rc2;
+    }
+    return rc;
 }
 
 void ur_frame_join_async(ur_frame* f) { if (f) f->Cmd.JoinAsyncCompute(); }

@@ -1,0 +1,92 @@
+// The tail of the HZB chain as device code shared by two launch forms: `hzb_tail_kernel` (csrc/hzb.hip, one workgroup of
+// its own) and the streaming lighting kernel's extra workgroup (csrc/lighting.hip) when the frame driver lets the tail ride
+// along with the Lighting launch. Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ur {
+
+__device__ __forceinline__ float hzb_min4(float a, float b, float c, float d) { return fminf(fminf(a, b), fminf(c, d)); }
+
+// ---- the tail of the chain in ONE single-workgroup launch ----------------------------------------------------------------
+// Once a mip has <= 16384 texels every remaining level fits in LDS, and the reference's further dispatches (<= 4 mips
+// each) are a few microseconds of launch latency apiece for microseconds of work in total. The values are those of the
+// reference's grouping all the same: a level whose index is a multiple of four is the FIRST level of a reference dispatch
+// — it reads its parent through clamped 2x2 footprints (SampleDepth, BuildHZB.hlsl:34-39) — every other level takes the
+// 2x2 of its parent's lanes, where an out-of-range parent lane holds 1.0 if the parent was a first level and 0.0
+// otherwise (BuildHZB.hlsl:47,81,104).
+
+template <uint32_t TRIPS, class P>
+__device__ __forceinline__ void tail_first_level(const P& p, float* bufA)
+{
+    const uint32_t tid = threadIdx.x, W = p.W[0], n = W * p.H[0];
+    const bool first = (p.first_mip & 3u) == 0u;                     // first level of a reference dispatch: clamped reads
+    const float fill = ((p.first_mip - 1u) & 3u) == 0u ? 1.0f : 0.0f; // otherwise: what an out-of-range parent lane holds
+    float t[TRIPS][4];
+    bool in1[TRIPS], in2[TRIPS];
+#pragma unroll
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t i = min(tid + k * 1024u, n - 1u); // clamped into the level: no branch separates the loads
+        const uint32_t y = W == 1u ? i : __umulhi(i, p.magic[0]), x = i - y * W;
+        in1[k] = first || 2u * x + 1u < p.SW;
+        in2[k] = first || 2u * y + 1u < p.SH;
+        const uint32_t x0 = min(2u * x, p.SW - 1u), x1 = min(2u * x + 1u, p.SW - 1u);
+        const uint32_t y0 = min(2u * y, p.SH - 1u) * p.SW, y1 = min(2u * y + 1u, p.SH - 1u) * p.SW;
+        t[k][0] = p.src[y0 + x0]; t[k][1] = p.src[y0 + x1];
+        t[k][2] = p.src[y1 + x0]; t[k][3] = p.src[y1 + x1];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t i = tid + k * 1024u;
+        if (i < n) {
+            const float v = hzb_min4(t[k][0], in1[k] ? t[k][1] : fill, in2[k] ? t[k][2] : fill, (in1[k] && in2[k]) ? t[k][3] : fill);
+            bufA[i] = v;
+            p.dst[0][i] = v;
+        }
+    }
+}
+
+// 1024 threads; bufA holds kTailTexels floats, bufB half as many (LDS)
+template <class P> // P = HzbTail in any address space
+__device__ __forceinline__ void hzb_tail_run(const P& p, float* bufA, float* bufB)
+{
+    const uint32_t tid = threadIdx.x;
+    // first level of the tail: parent in global memory. Every load of the thread is issued before the first reduction:
+    // one memory latency (8 or 16 texels x 4 taps).
+    if (p.W[0] * p.H[0] <= kTailTexels / 2u) tail_first_level<kTailTexels / 2048u>(p, bufA);
+    else tail_first_level<kTailTexels / 1024u>(p, bufA);
+    __syncthreads();
+    for (uint32_t l = 1; l < p.levels; ++l) { // uniform
+        const float* par = (l & 1u) ? bufA : bufB;
+        float* cur = (l & 1u) ? bufB : bufA;
+        const uint32_t W = p.W[l], H = p.H[l], PW = p.W[l - 1], PH = p.H[l - 1];
+        const uint32_t m = p.first_mip + l;
+        const bool first = (m & 3u) == 0u;                     // first level of a reference dispatch: clamped reads
+        const float fill = ((m - 1u) & 3u) == 0u ? 1.0f : 0.0f; // what an out-of-range parent lane holds otherwise
+        const uint32_t mg = p.magic[l];
+        for (uint32_t i = tid; i < W * H; i += 1024u) {
+            const uint32_t y = W == 1u ? i : __umulhi(i, mg), x = i - y * W;
+            float v;
+            if (first) {
+                const uint32_t x0 = min(2u * x, PW - 1u), x1 = min(2u * x + 1u, PW - 1u);
+                const uint32_t y0 = min(2u * y, PH - 1u), y1 = min(2u * y + 1u, PH - 1u);
+                v = hzb_min4(par[y0 * PW + x0], par[y0 * PW + x1], par[y1 * PW + x0], par[y1 * PW + x1]);
+            } else {
+                const uint32_t x0 = 2u * x, x1 = x0 + 1u, y0 = 2u * y, y1 = y0 + 1u;
+                const float a = par[y0 * PW + x0]; // (2x, 2y) is always in range
+                const float b = x1 < PW ? par[y0 * PW + x1] : fill;
+                const float c = y1 < PH ? par[y1 * PW + x0] : fill;
+                const float d = (x1 < PW && y1 < PH) ? par[y1 * PW + x1] : fill;
+                v = hzb_min4(a, b, c, d);
+            }
+            cur[i] = v;
+            p.dst[l][i] = v;
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace ur

@@ -20,6 +20,7 @@
 
 #include "ur_internal.h"
 #include "ur_device.h"
+#include "hzb_tail.h"
 
 #include <algorithm>
 #include <cmath>
@@ -36,6 +37,7 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 // The launch-uniform values of the streaming kernel's loop. The hot ones stay in SGPRs across the loop; cold paths (sky
 // constants, shadow slow path, partial tiles) re-read theirs from the kernarg segment when they run (fresh_params()).
 struct StreamHot {
+    uint32_t groups; // lighting workgroups of the launch (a workgroup with this index, if any, runs the deferred HZB tail)
     uint32_t tilesX, numTiles, tilesXMagic, W, rows, row0, irrN0, irrRowBytes; // tilesXMagic: tile / tilesX = (tile * magic) >> 32
     uint32_t chunkShift; // log2 of the tiles a workgroup is dealt at a time
     float invW2, invH2, invP11, nInvP22;      // ray: ra = ndc.x * invP11, rb = ndc.y * nInvP22 (= -1/P22)
@@ -661,7 +663,7 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 #endif
 
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
-__global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p)
+__global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p, ur::HzbTail hzbTail)
 {
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the per-tile kernel");
 #ifdef UR_STAMPS
@@ -671,6 +673,19 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 #endif
     ur::warm_kernarg<sizeof(LightingParams)>(); // (ur_device.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x >= p.hot.groups) { // uniform: the one extra workgroup of a launch that carries a deferred HZB tail (ur_defer_hzb_tail)
+        if constexpr (WPB == 16) {
+            static_assert(kLdsTiles + 16u * 2u * kTileBytes >= (ur::kTailTexels + ur::kTailTexels / 2u) * sizeof(float), "the tail's two level buffers fit the launch's LDS");
+            float* bufA = reinterpret_cast<float*>(smem);
+            // read through the kernarg segment behind an opaque pointer: nothing of the 264-byte argument is live outside this branch
+            auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            typedef const __attribute__((address_space(4))) ur::HzbTail* KTail;
+            static_assert(sizeof(LightingParams) % 8 == 0, "the second kernel argument follows the first without padding");
+            ur::hzb_tail_run(*(KTail)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams)), bufA, bufA + ur::kTailTexels);
+        }
+        return;
+    }
     float* srgb = reinterpret_cast<float*>(smem + kLdsSrgb);
     MipEntry* mipT = reinterpret_cast<MipEntry*>(smem + kLdsMip);
     float4a* irrT = reinterpret_cast<float4a*>(smem + kLdsIrr);
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     // arbitration lets some waves of a workgroup run up to twice as fast as others (measured with in-kernel stamps); with
     // a static split the slow ones set the kernel's duration, with the counter all of them finish together.
     // Claims c = wave and c = WPB + wave are static (the two tiles of the prologue).
-    const uint32_t cs = p.hot.chunkShift, chunkStride = gridDim.x << cs, base = blockIdx.x << cs, cmask = (1u << cs) - 1u;
+    const uint32_t cs = p.hot.chunkShift, chunkStride = p.hot.groups << cs, base = blockIdx.x << cs, cmask = (1u << cs) - 1u;
     // claim c -> tile (c >> cs) * chunkStride + base + (c & cmask): chunks of 2^cs consecutive tiles, dealt round-robin
     uint32_t tile = (wave >> cs) * chunkStride + base + (wave & cmask);
     uint32_t tile1 = ((wave + WPB) >> cs) * chunkStride + base + ((wave + WPB) & cmask);
@@ -1124,12 +1139,21 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     StreamHot& h = p.hot;
     h.tilesX = p.W / 16u;
     h.numTiles = h.tilesX * ((p.rows + 3u) / 4u);
-    const uint32_t groups = std::min<uint32_t>((uint32_t)ctx->cu_count, (h.numTiles + WPB - 1) / WPB);
+    // A deferred HZB tail (ur_defer_hzb_tail) rides along as one extra 1024-thread workgroup on a CU of its own: the
+    // lighting workgroups give up one CU (0.4 % of their throughput) and the frame saves a ~5 us single-workgroup launch.
+    ur::HzbTail tail{};
+    const bool carry_tail = ctx->hzb_tail_pending && WPB == 16 && ctx->cu_count >= 16;
+    if (carry_tail) {
+        tail = ctx->pending_tail;
+        ctx->hzb_tail_pending = false;
+    }
+    const uint32_t groups = std::min<uint32_t>((uint32_t)ctx->cu_count - (carry_tail ? 1u : 0u), (h.numTiles + WPB - 1) / WPB);
+    h.groups = groups;
     // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
     static const int chunk_shift = env_int("UR_LIGHTING_CHUNK_SHIFT", 2); // 4K: chunks of 16 / 4 / 1 tiles -> 75.4 / 74.6 / 79.1 us
     h.chunkShift = (uint32_t)std::min(std::max(chunk_shift, 0), 4);
-    hipLaunchKernelGGL(kern, dim3(groups), dim3(64 * WPB), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3(groups + (carry_tail ? 1u : 0u)), dim3(64 * WPB), lds, ctx->stream, p, tail);
     return UR_OK;
 }
 

@@ -125,10 +125,24 @@ ur_ctx* ur_create(int device, void* stream)
 void ur_destroy(ur_ctx* ctx)
 {
     if (!ctx) return;
+    (void)ur::flush_hzb_tail(ctx);
     if (ctx->srgb_table) (void)hipFree(ctx->srgb_table);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
     delete ctx;
+}
+
+int ur_defer_hzb_tail(ur_ctx* ctx, int enable)
+{
+    if (!ctx) { set_error("ur_defer_hzb_tail: null context"); return UR_EINVAL; }
+    ctx->defer_hzb_tail = enable != 0;
+    return enable ? UR_OK : ur::flush_hzb_tail(ctx);
+}
+
+int ur_flush(ur_ctx* ctx)
+{
+    if (!ctx) { set_error("ur_flush: null context"); return UR_EINVAL; }
+    return ur::flush_hzb_tail(ctx);
 }
 
 int ur_reserve(ur_ctx* ctx, uint32_t max_instances)

@@ -8,6 +8,18 @@
 
 #include "../../include/ur_hotpath.h"
 
+namespace ur {
+// Arguments of the single-workgroup tail of the HZB chain (csrc/hzb_tail.h): the levels from `first_mip` on.
+constexpr uint32_t kTailMaxLevels = 12, kTailTexels = 16384;
+struct HzbTail {
+    const float* src; // mip first_mip - 1 (global memory, written by the previous launch)
+    uint32_t SW, SH, first_mip, levels;
+    float* dst[kTailMaxLevels];
+    uint32_t W[kTailMaxLevels], H[kTailMaxLevels];
+    uint32_t magic[kTailMaxLevels]; // i / W[l] == __umulhi(i, magic[l]) for i < 16384 (magic = 2^32 / W + 1)
+};
+} // namespace ur
+
 struct ur_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -18,6 +30,11 @@ struct ur_ctx {
     // sRGB8 -> linear table (256 floats), uploaded once
     float* srgb_table = nullptr;
     int cu_count = 256;
+    // The HZB tail may ride along with the next streaming Lighting launch as one extra workgroup (ur_defer_hzb_tail):
+    // its single workgroup is ~5 us of latency during which the other 255 CUs would idle.
+    bool defer_hzb_tail = false;
+    bool hzb_tail_pending = false;
+    ur::HzbTail pending_tail{};
 };
 
 namespace ur {
@@ -43,5 +60,7 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* scene, const ur_sky_c
                     const ur_half4* gbuf_b, const uint32_t* gbuf_c, const float* depth, const ur_lighting_tables* tables,
                     ur_half4* hdr, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows, int mode);
 enum { UR_MODE_LIGHTING = 0, UR_MODE_SKY = 1, UR_MODE_FUSED = 2 };
+// launches a deferred HZB tail on its own if one is pending (ur_flush and every launch that reads or rewrites the HZB)
+int flush_hzb_tail(ur_ctx* ctx);
 
 } // namespace ur

@@ -76,6 +76,13 @@ class HotPath:
     def reserve(self, max_instances: int):
         _lib.check(self._L.ur_reserve(self._ctx, max_instances), "ur_reserve")
 
+    def defer_hzb_tail(self, enable: bool):
+        """Hold back the single-workgroup tail of build_hzb so that it rides along with the next streaming lighting launch."""
+        _lib.check(self._L.ur_defer_hzb_tail(self._ctx, int(enable)), "ur_defer_hzb_tail")
+
+    def flush(self):
+        _lib.check(self._L.ur_flush(self._ctx), "ur_flush")
+
     # ---- BuildHZB ----
     def build_hzb(self, depth: torch.Tensor, hzb: torch.Tensor, layout: HzbLayout):
         assert depth.dtype == torch.float32 and hzb.dtype == torch.float32 and hzb.numel() >= layout.total

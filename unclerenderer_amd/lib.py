@@ -104,6 +104,7 @@ class FrameResources(C.Structure):
 UR_FRAME_INDIRECT_DRAW, UR_FRAME_HZB, UR_FRAME_DEPTH_PREPASS, UR_FRAME_SHADOWS, UR_FRAME_SKY = 0x1, 0x2, 0x4, 0x8, 0x10
 UR_FRAME_FUSE_LIGHTING_SKY, UR_FRAME_GPU_TIMING, UR_FRAME_GRAPH_DUMP, UR_FRAME_BARRIER_LOGS = 0x20, 0x40, 0x80, 0x100
 UR_FRAME_ASYNC_COMPUTE, UR_FRAME_ASYNC_NO_JOIN, UR_FRAME_TONEMAP, UR_FRAME_TIME_LIGHTING = 0x200, 0x400, 0x800, 0x1000
+UR_FRAME_HZB_TAIL_WITH_LIGHTING = 0x2000
 UR_FRAME_DEFAULT = UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY
 
 assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
@@ -116,6 +117,8 @@ SIGNATURES = {
     "ur_create": (_VP, [C.c_int, _VP]),
     "ur_destroy": (None, [_VP]),
     "ur_reserve": (C.c_int, [_VP, _U32]),
+    "ur_defer_hzb_tail": (C.c_int, [_VP, C.c_int]),
+    "ur_flush": (C.c_int, [_VP]),
     "ur_last_error": (C.c_char_p, []),
     "ur_version": (C.c_char_p, []),
     "ur_hzb_layout": (_U32, [_U32, _U32, C.POINTER(MipDesc), C.POINTER(_U32)]),
