@@ -358,6 +358,29 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
     out["cull_1m"] = {"instances": n, "visible": visible, "frustum_culled": frustum_culled, "occluded": occluded,
                       "median_us": med * 1e6, "instances_per_s": n / med, "algorithmic_GBps": cull_bytes / med / 1e9,
                       "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS}
+    # the rows behind the path: Tonemap and TemporalAA at the frame size, back-to-back launches over
+    # three cold buffer sets between ONE event pair
+    W, H, ring = args.width, args.height, 3
+    hdr = [(torch.rand((H, W, 4), device=f"cuda:{dev}") * 4.0).to(torch.float16).view(torch.int16) for _ in range(ring)]
+    hist = [(torch.rand((H, W, 4), device=f"cuda:{dev}") * 4.0).to(torch.float16).view(torch.int16) for _ in range(ring)]
+    out8 = [torch.zeros((H, W), dtype=torch.int32, device=f"cuda:{dev}") for _ in range(ring)]
+    out16 = [torch.zeros((H, W, 4), dtype=torch.int16, device=f"cuda:{dev}") for _ in range(ring)]
+
+    def loop(fn, iters=600):
+        for k in range(400):  # ~10-20 ms of work before the clock is the sustained one
+            fn(k)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for k in range(iters):
+            fn(k)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / iters
+
+    t = loop(lambda k: hp.tonemap(hdr[k % ring], out8[k % ring], W, H))
+    out["tonemap"] = {"size": f"{W}x{H}", "us": t * 1e6, "GBps": 12 * W * H / t / 1e9, "frac_hbm": 12 * W * H / t / 1e9 / HBM_PEAK_GBS}
+    t = loop(lambda k: hp.temporal_aa(hdr[k % ring], hist[k % ring], out16[k % ring], 0.9, True, W, H))
+    out["temporal_aa"] = {"size": f"{W}x{H}", "us": t * 1e6, "GBps": 24 * W * H / t / 1e9, "frac_hbm": 24 * W * H / t / 1e9 / HBM_PEAK_GBS}
     return out
 
 
