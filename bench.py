@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--separate-hzb-tail", action="store_true",
                     help="launch the single-workgroup tail of Build HZB on its own (three visibility launches per frame) instead of "
                          "letting it ride along with the Lighting launch as an extra workgroup")
+    ap.add_argument("--explicit-stream", action="store_true", help="run everything on one explicitly created stream instead of the default (null) stream")
     ap.add_argument("--graph", action="store_true",
                     help="capture one frame per buffer set in a HIP graph (torch.cuda.CUDAGraph) and replay it; frames that carry the "
                          "Lighting event pair are still submitted eagerly")
@@ -93,7 +94,7 @@ def main():
         raise SystemExit(f"height {H} not divisible by {N} ranks")
     band = H // N
     row0 = rank * band
-    if args.graph:
+    if args.graph or args.explicit_stream:
         # stream capture is not allowed on the legacy default stream: the whole run uses one explicit stream
         torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
     hp = HotPath(local_rank)
