@@ -124,6 +124,31 @@ def test_tail_flushed_by_flush_cull_rebuild_and_disable(hotpath, oracle):
         hotpath.defer_hzb_tail(False)
 
 
+@pytest.mark.parametrize("w,h", [(6001, 3999), (7680, 4320)])
+def test_large_chain_two_launches_when_deferred(hotpath, w, h):
+    """Mip 4 does not fit the tail's LDS but mip 5 does: with the tail held back the first launch produces five levels and
+    the tail reads mip 4 from memory (two launches instead of three). Same bits as the plain build."""
+    import torch
+    from unclerenderer_amd.hotpath import HzbLayout
+    lay = HzbLayout(w, h)
+    depth = torch.rand(h * w, device="cuda")
+    depth[torch.rand(h * w, device="cuda") < 0.1] = 0.0
+    ref = torch.full((lay.total,), -1.0, device="cuda")
+    hotpath.build_hzb(depth, ref, lay)
+    hzb = torch.full((lay.total,), -1.0, device="cuda")
+    hotpath.defer_hzb_tail(True)
+    try:
+        hotpath.build_hzb(depth, hzb, lay)
+        torch.cuda.synchronize()
+        off5 = lay.as_list()[5][0]
+        assert float(hzb[off5]) == -1.0 and float(hzb[lay.as_list()[4][0]]) != -1.0, "mip 4 written by the first launch, mip 5 held back"
+        hotpath.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(hzb, ref)
+    finally:
+        hotpath.defer_hzb_tail(False)
+
+
 def test_frame_flag_gives_the_same_frame(hotpath):
     import torch
     from unclerenderer_amd import hostmath, lib, synth

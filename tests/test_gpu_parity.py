@@ -22,7 +22,8 @@ def _torch():
 # ---------------------------------------------------------------------------------------------------------------------
 # BuildHZB
 # ---------------------------------------------------------------------------------------------------------------------
-HZB_SIZES = [(1, 1), (2, 2), (3, 5), (17, 9), (64, 64), (129, 67), (512, 512), (1920, 1080), (1000, 3), (5, 300), (2, 33), (4096, 16)]
+HZB_SIZES = [(1, 1), (2, 2), (3, 5), (17, 9), (64, 64), (129, 67), (512, 512), (1920, 1080), (1000, 3), (5, 300), (2, 33), (4096, 16),
+             (6001, 3999), (7680, 4320)]  # the last two: mip 4 is too large for the tail's LDS (three launches)
 
 
 @pytest.mark.parametrize("w,h", HZB_SIZES)

@@ -173,6 +173,11 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
         // the first launch also produces mip 4 when a tail launch follows: the tail then starts from 1/4 of the texels
         // (a single workgroup reads ~25 GB/s: 130 KB of mip 3 at 4K would be 5 us on its own)
         if (mip == 0 && mip_count > 4u && (uint64_t)mips[4].width * mips[4].height <= kTailTexels) n = 5u;
+        // What has to fit the tail's LDS is ITS first level, mip 5; its parent, mip 4, is read from global memory. At 8K
+        // that is 130 KB through one workgroup: a 9-us tail, 1.5 us SLOWER than a third launch when it runs on its own
+        // (41.6 against 40.0 us) - but free when it rides along with the Lighting launch.
+        else if (mip == 0 && ctx->defer_hzb_tail && mip_count > 5u && (uint64_t)mips[5].width * mips[5].height <= kTailTexels &&
+                 mip_count - 5u <= kTailMaxLevels) n = 5u;
         HzbDispatch d{};
         if (mip == 0) {
             d.src = depth;
