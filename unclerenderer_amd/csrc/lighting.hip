@@ -1147,7 +1147,10 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
         tail = ctx->pending_tail;
         ctx->hzb_tail_pending = false;
     }
-    const uint32_t groups = std::min<uint32_t>((uint32_t)ctx->cu_count - (carry_tail ? 1u : 0u), (h.numTiles + WPB - 1) / WPB);
+    // UR_LIGHTING_LEAVE_CUS = n leaves n CUs to kernels of other streams (the graph's async-compute passes): the persistent
+    // workgroups otherwise fill every CU's register file and nothing runs beside them
+    static const int leave_cus = std::min(std::max(env_int("UR_LIGHTING_LEAVE_CUS", 0), 0), 128);
+    const uint32_t groups = std::min<uint32_t>((uint32_t)ctx->cu_count - (carry_tail ? 1u : 0u) - (uint32_t)leave_cus, (h.numTiles + WPB - 1) / WPB);
     h.groups = groups;
     // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
