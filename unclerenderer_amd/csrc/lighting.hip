@@ -11,7 +11,8 @@
 // Two kernels share that arithmetic:
 //   * lighting_stream_kernel (second half of this file, the default): persistent workgroups, G-buffer tiles prefetched into
 //     LDS by DMA, side tables in LDS, work claimed from an LDS counter, instruction selection tuned to gfx950's VALU issue
-//     rules (DESIGN.md section 3.3 has the measurements behind every choice);
+//     rules (DESIGN.md section 3.3 has the measurements behind every choice). A launch may carry one extra workgroup
+//     that runs the held-back tail of the HZB chain on a CU of its own (ur_defer_hzb_tail, csrc/hzb_tail.h);
 //   * lighting_kernel (first half): one workgroup per 64 x 4 pixels, plain loads; sky-only launches and every
 //     configuration the streaming kernel declines (launch_lighting() at the end decides per launch, never per row).
 // Every per-launch uniform the HLSL recomputes per pixel is folded on the host: gfx950 has no scalar fp32 ALU. The view
