@@ -76,3 +76,23 @@ def test_null_context_is_einval(urlib):
     assert urlib.ur_reserve(None, 10) == lib.UR_EINVAL
     assert urlib.ur_frame_render(None, None, None, None, None, 0) == lib.UR_EINVAL
     assert b"gfx950" in urlib.ur_version()
+
+
+def test_product_never_reaches_for_the_oracle():
+    """The oracle is test infrastructure: nothing under unclerenderer_amd/ (Python or native) may import, include, link or
+    load it, and the shipped library must not depend on liburoracle."""
+    import re
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|#\s*include\s*[\"<][^\">]*oracle)|liburoracle|oracle/_build|oracle\.oracle", re.M)
+    bad = []
+    for f in (root / "unclerenderer_amd").rglob("*"):
+        if f.is_file() and f.suffix in {".py", ".hip", ".cpp", ".h", ".hpp"} and "_build" not in f.parts:
+            if pat.search(f.read_text(errors="replace")):
+                bad.append(str(f.relative_to(root)))
+    assert not bad, bad
+    lib = root / "unclerenderer_amd" / "csrc" / "_build" / "libur_hotpath.so"
+    if lib.exists():
+        needed = subprocess.run(["readelf", "-d", str(lib)], capture_output=True, text=True).stdout
+        assert "oracle" not in needed
