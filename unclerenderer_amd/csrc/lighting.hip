@@ -608,7 +608,13 @@ __device__ __forceinline__ void tile_prefetch(P p, uint32_t W, uint32_t rows, co
 {
     const uint32_t origin = (ty * 4u) * W + tx * 16u, rowsLeft = rows - ty * 4u; // uniform
     if (rowsLeft >= 4u) tile_dma(full, origin, lds_dst);
-    else tile_dma(tile_src<MODE>(p, lane, rowsLeft - 1u), origin, lds_dst);
+    else {
+        // cold path (the one partial tile row of a band): the lane index goes through an opaque move so that nothing derived
+        // from it is hoisted out of the persistent loop and kept live (it would be the loop's one spilled value)
+        uint32_t l = lane;
+        asm volatile("" : "+v"(l));
+        tile_dma(tile_src<MODE>(p, l, rowsLeft - 1u), origin, lds_dst);
+    }
 }
 
 struct __attribute__((aligned(16))) float4a { float x, y, z, w; };
