@@ -52,14 +52,36 @@ def parse():
                     help="capture one frame per buffer set in a HIP graph (torch.cuda.CUDAGraph) and replay it; frames that carry the "
                          "Lighting event pair are still submitted eagerly")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each frame's HDR all-gather before the next frame starts")
+    ap.add_argument("--gather-ldr", action="store_true",
+                    help="add the Tonemap pass behind Lighting+Sky (Tonemap.hlsl) and, with N > 1, all-gather the tonemapped RGBA8 bands "
+                         "(4 B/pixel over xGMI) instead of the RGBA16F ones (8 B/pixel)")
     ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 1M-instance cull and iid side measurements")
     return ap.parse_args()
 
 
+def _self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N rank processes ourselves, as a CHILD
+    `python -m torch.distributed.run`, before this process has imported torch or touched a GPU (a process that has
+    initialised HIP must never exec or fork GPU work on this pool). Rank 0's JSON line goes to the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -71,9 +93,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+        args.gpus = world  # launched under torch.distributed.run: the launcher's world size is the truth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # UR_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices;
@@ -133,7 +153,8 @@ def main():
     assert (env_base, env_mips) == (256, 9)
     gen_s = time.time() - t_gen
 
-    tables = hp.make_tables(to_device(shadow, dev), hp.stage_env_cube(env, 256, 9), 256, 9, to_device(lut, dev))
+    d_env_cube, d_lut = hp.stage_env_cube(env, 256, 9), to_device(lut, dev)
+    tables = hp.make_tables(to_device(shadow, dev), d_env_cube, 256, 9, d_lut)
     lay = HzbLayout(W, H)
     ring = max(1, args.ring)
     sets = []
@@ -147,6 +168,9 @@ def main():
         s["depth_band"] = s["depth_full"][row0:row0 + band]
         # N == 1: shade straight into the frame; N > 1: shade a band buffer, RCCL gathers the bands into the frame
         s["hdr_band"] = s["hdr_full"][row0:row0 + band] if N == 1 else to_device(g.hdr, dev)
+        if args.gather_ldr:
+            s["ldr_full"] = torch.zeros((H, W), dtype=torch.int32, device=f"cuda:{dev}")
+            s["ldr_band"] = s["ldr_full"][row0:row0 + band] if N == 1 else torch.zeros((band, W), dtype=torch.int32, device=f"cuda:{dev}")
         sets.append(s)
 
     # Sponza cull: 25 commands sharing one AABB, sharded by instance range
@@ -170,13 +194,15 @@ def main():
     flags = urlib.UR_FRAME_DEFAULT | urlib.UR_FRAME_FUSE_LIGHTING_SKY
     if not args.separate_hzb_tail:
         flags |= urlib.UR_FRAME_HZB_TAIL_WITH_LIGHTING  # (ignored with --async-compute)
+    if args.gather_ldr:
+        flags |= urlib.UR_FRAME_TONEMAP
     if args.async_compute:
         # visibility passes on the async-compute stream; joined once before the timed region closes (nothing on the
         # main stream consumes their outputs or overwrites their inputs inside the loop)
         flags |= urlib.UR_FRAME_ASYNC_COMPUTE | urlib.UR_FRAME_ASYNC_NO_JOIN
     for s in sets:
         s["res"] = Frame.resources(W, H, row0, band, s["A"], s["B"], s["C"], s["depth_band"], s["hdr_band"], s["depth_full"], hzb, lay, tables,
-                                   d_bounds, d_args, i1 - i0, i0, d_vis, d_cnt, None)
+                                   d_bounds, d_args, i1 - i0, i0, d_vis, d_cnt, None, s.get("ldr_band"))
 
     # roofline leg: the Lighting pass of every timed frame is bracketed by a HIP event pair on the stream it is launched on
     timed_flags = flags if args.no_light_events else (flags | urlib.UR_FRAME_TIME_LIGHTING)
@@ -197,7 +223,10 @@ def main():
         if N > 1:
             # RCCL all-gather of the bands on the communication stream, behind this frame's passes; the next frames (other
             # buffer sets of the ring) are shaded while it runs — frames in flight, as the reference keeps three
-            s["gather"] = urdist.allgather_hdr(s["hdr_full"], s["hdr_band"], async_op=not args.sync_gather)
+            if args.gather_ldr:
+                s["gather"] = urdist.allgather_rows(s["ldr_full"], s["ldr_band"], async_op=not args.sync_gather)
+            else:
+                s["gather"] = urdist.allgather_hdr(s["hdr_full"], s["hdr_band"], async_op=not args.sync_gather)
 
     def fence():
         for s in sets:
@@ -222,7 +251,10 @@ def main():
             with torch.cuda.graph(g_, stream=torch.cuda.current_stream()):
                 frame.render(s["res"], cull_consts, fc.scene, fc.sky, flags)
             s["graph"] = g_
-    for k in range(max(args.warmup, args.min_warmup)):
+    # Untimed frames, in this order: a clock ramp of max(0, min_warmup - W) frames, the host-cost probe's 32, then the W
+    # warm-up steps the caller asked for, then the K timed ones. All of them are reported (clock_ramp_frames, warmup).
+    ramp_frames = max(0, args.min_warmup - args.warmup)
+    for k in range(ramp_frames):
         step(k, False)
     fence()
     # host cost of one frame's submission with an empty queue (no back-pressure): if this approaches ms_per_step the run
@@ -231,6 +263,9 @@ def main():
     for k in range(32):
         step(k, False)
     host_unthrottled_ms = (time.perf_counter() - th) / 32 * 1e3
+    ramp_frames += 32
+    for k in range(args.warmup):
+        step(k, False)
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -271,7 +306,9 @@ def main():
         "unit": "Mpixels/s",
         "n_gpus": N,
         "steps": args.steps,
-        "warmup": args.warmup,
+        "warmup": args.warmup,  # the W warm-up steps, run immediately before the timed region ...
+        "clock_ramp_frames": ramp_frames,  # ... and the untimed frames run BEFORE those (clock ramp to --min-warmup, 32 for the host-cost probe)
+        "untimed_frames_total": ramp_frames + args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "host_submit_ms_per_step": t_enqueued / args.steps * 1e3,
         "host_submit_unthrottled_ms_per_step": host_unthrottled_ms,
@@ -282,7 +319,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"Sponza {W}x{H} full pipeline: cull(25) + BuildHZB({lay.count} mips) + DeferredLighting+Sky fused"
-                        + (f", {N} row bands + RCCL all-gather of HDR" + (" (overlapped with the next frames)" if not args.sync_gather else "") if N > 1 else ""),
+                        + (" + Tonemap" if args.gather_ldr else "")
+                        + (f", {N} row bands + RCCL all-gather of " + ("tonemapped RGBA8" if args.gather_ldr else "RGBA16F HDR") + (" (overlapped with the next frames)" if not args.sync_gather else "") if N > 1 else ""),
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
@@ -305,7 +343,11 @@ def main():
             pass
 
     if rank == 0 and N == 1 and not args.no_extras:
-        result["extras"] = side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath, dev)
+        result["extras"] = ex = side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath, dev, (d_env_cube, d_lut))
+        # the same kernel on SURVEY.md §8d's own generator travels in the roofline block too (the headline input is the
+        # coherent "scene" G-buffer; on independent-per-pixel normals every lane gathers its own cube/shadow line)
+        result["roofline"]["other_inputs"] = {k: {"us": ex[k]["us"], "achieved": ex[k]["GBps"], "frac": ex[k]["frac_hbm"]}
+                                              for k in ("lighting_iid", "lighting_1080p_scene", "lighting_8k_scene")}
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(fc, g, shadow, env, lut, bounds, lay, W, H)
     if rank == 0:
@@ -330,14 +372,48 @@ def _time_events(torch, fn, iters, warm=5):
     return float(np.median(t)), float(t.min())
 
 
-def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath, dev):
+def tables_for(hp, to_device, synth, fc, kind, dev, env_dev):
+    """Lighting side tables: the scene generator's shadow map (or the noise one for the iid G-buffer), the staged cube, the LUT."""
+    if kind == "scene":
+        shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+    else:
+        shadow = synth.shadow_map_noise(2048, synth.SEED_BASE + 3)
+    return hp.make_tables(to_device(shadow, dev), env_dev[0], 256, 9, env_dev[1])
+
+
+def light_leg(hp, torch, to_device, fc, g, tables, W, H, dev, ring, iters, warm):
+    """One fused Lighting+Sky launch per iteration over `ring` cold buffer sets; per-launch time from ONE event pair."""
+    sets = [dict(A=to_device(g.A, dev), B=to_device(g.B, dev), C=to_device(g.C, dev), D=to_device(g.depth, dev), hdr=to_device(g.hdr, dev)) for _ in range(ring)]
+    n_sky = int((g.depth == 0).sum())
+    nbytes = 40 * (g.depth.size - n_sky) + 12 * n_sky
+
+    def fn(k):
+        s = sets[k % ring]
+        hp.deferred_lighting_sky(fc.scene, fc.sky, s["A"], s["B"], s["C"], s["D"], tables, s["hdr"], W, H)
+    for k in range(warm):  # the chip needs ~10-20 ms of work before its clock is the sustained one
+        fn(k)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for k in range(iters):
+        fn(k)
+    b.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(b) * 1e-3 / iters
+    del sets
+    torch.cuda.empty_cache()
+    return {"size": f"{W}x{H}", "background_fraction": round(n_sky / g.depth.size, 4), "bytes_per_launch": nbytes, "us": t * 1e6,
+            "GBps": nbytes / t / 1e9, "frac_hbm": nbytes / t / 1e9 / HBM_PEAK_GBS, "mpixels_per_s": W * H / t / 1e6, "launches": iters}
+
+
+def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath, dev, env_dev):
     """Culled instances/s on BASELINE config 5's instance set (1 M AABBs against an 8K-frame HZB) and per-kernel times."""
     out = {}
     W8, H8 = 7680, 4320
     n = args.cull_instances
     fc8 = hostmath.build_frame_constants("sponza", W8, H8)
     lay8 = HzbLayout(W8, H8)
-    depth8 = to_device(synth.gbuffer_scene(fc8.view, fc8.proj, fc8.camera_position, W8, H8, synth.SEED_BASE + 5).depth, dev)
+    g8 = synth.gbuffer_scene(fc8.view, fc8.proj, fc8.camera_position, W8, H8, synth.SEED_BASE + 5)
+    depth8 = to_device(g8.depth, dev)
     hzb8 = torch.zeros(lay8.total, dtype=torch.float32, device=f"cuda:{dev}")
     med, mn = _time_events(torch, lambda: hp.build_hzb(depth8, hzb8, lay8), 30)
     hzb_bytes = 4 * (W8 * H8 + lay8.mip_texels())
@@ -359,6 +435,22 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
     out["cull_1m"] = {"instances": n, "visible": visible, "frustum_culled": frustum_culled, "occluded": occluded,
                       "median_us": med * 1e6, "instances_per_s": n / med, "algorithmic_GBps": cull_bytes / med / 1e9,
                       "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS}
+    # ---- fused Lighting+Sky on the other G-buffers the contract names: the independent-per-pixel generator
+    #      at the frame size (the stress case: every lane gathers its own cube / LUT / shadow line), C2's 1920x1080 and C5's
+    #      7680x4320, Sponza constants, shipped IBL tables. Back-to-back launches over cold buffer sets between ONE event pair.
+    del depth8, hzb8, bounds, d_args, d_vis
+    torch.cuda.empty_cache()
+    out["lighting_8k_scene"] = light_leg(hp, torch, to_device, fc8, g8, tables_for(hp, to_device, synth, fc8, "scene", dev, env_dev), W8, H8, dev, ring=2, iters=150, warm=60)
+    del g8
+    fc2 = hostmath.build_frame_constants("sponza", 1920, 1080)
+    g2 = synth.gbuffer_scene(fc2.view, fc2.proj, fc2.camera_position, 1920, 1080, synth.SEED_BASE + 2)
+    out["lighting_1080p_scene"] = light_leg(hp, torch, to_device, fc2, g2, tables_for(hp, to_device, synth, fc2, "scene", dev, env_dev), 1920, 1080, dev, ring=8, iters=1200, warm=800)
+    W, H = args.width, args.height
+    fci = hostmath.build_frame_constants("sponza", W, H)
+    gi = synth.gbuffer_iid(W, H, synth.SEED_BASE + 3)
+    out["lighting_iid"] = light_leg(hp, torch, to_device, fci, gi, tables_for(hp, to_device, synth, fci, "iid", dev, env_dev), W, H, dev, ring=3, iters=200, warm=80)
+    del gi, g2
+    torch.cuda.empty_cache()
     # the rows behind the path: Tonemap and TemporalAA at the frame size, back-to-back launches over
     # three cold buffer sets between ONE event pair
     W, H, ring = args.width, args.height, 3

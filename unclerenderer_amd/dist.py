@@ -6,6 +6,8 @@ the GPU box, "gloo" in the CPU tests). The reference is single-GPU; this is new 
   * CullIndirectArgs: contiguous instance ranges; the per-rank visible lists are already ascending and carry global
     indices (index_base), so concatenating them in rank order is the single-GPU list bit for bit. Counts are
     all-gathered first, then the lists are all-gathered padded to the largest count.
+  * Tonemap ahead of the gather: the band is tonemapped to R8G8B8A8 on the rank that shaded it and the
+    4-byte pixels are gathered instead (allgather_rows), halving the xGMI payload.
   * BuildHZB: replicated (every rank builds the full chain from the full depth) — no exchange.
 """
 from __future__ import annotations
@@ -54,6 +56,12 @@ def allgather_hdr(hdr_full: torch.Tensor, band: torch.Tensor, group=None, async_
     work = dist.all_gather_into_tensor(hdr_full.view(torch.uint8).view(-1), band.contiguous().view(torch.uint8).view(-1), group=group,
                                        async_op=async_op)
     return work if async_op else None
+
+
+def allgather_rows(full: torch.Tensor, band: torch.Tensor, group=None, async_op: bool = False):
+    """The same collective for any row-major image whose leading dimension is rows (the tonemapped R8G8B8A8 band,
+    Tonemap.hlsl:57-79: 4 B/pixel instead of the HDR band's 8): `full` (H, ...) on every rank, `band` this rank's H/N rows."""
+    return allgather_hdr(full, band, group=group, async_op=async_op)
 
 
 def allgather_visible(visible_idx: torch.Tensor, visible_count: torch.Tensor, group=None) -> tuple[torch.Tensor, int]:
