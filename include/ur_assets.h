@@ -42,6 +42,9 @@ int ur_dds_decode_rgba16f(const void* file, size_t size, const ur_dds_info* info
 int ur_dds_copy_rg16(const void* file, size_t size, const ur_dds_info* info, uint16_t* out);
 /* one BC6H block -> 16 texels (row-major 4x4); returns 0 for a reserved mode */
 int ur_bc6h_decode_block(const uint8_t block[16], int is_signed, ur_half4 out[16]);
+/* the block's mode number (1..14, 0 = reserved) and its unquantized endpoints r[4], g[4], b[4] (subset 0: [0],[1]; subset 1:
+ * [2],[3]; one-region modes leave [2],[3] zero) — what the decoder interpolates between; for tests and asset diagnostics */
+int ur_bc6h_block_endpoints(const uint8_t block[16], int is_signed, int32_t endpoints[12]);
 
 #ifdef __cplusplus
 }

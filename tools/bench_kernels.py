@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--cull", action="store_true")
     ap.add_argument("--no-light", action="store_true")
     ap.add_argument("--post", action="store_true", help="the rows behind the path: Tonemap (12 B/pixel) and TemporalAA resolve (24 B/pixel)")
+    ap.add_argument("--cache", default="", help="directory for the generated inputs (npz): repeated runs on one box skip the generators")
+    ap.add_argument("--no-shadows", action="store_true", help="ShadowStrength = 0: the SHADOWS=false instantiation")
+    ap.add_argument("--tag", default="", help="printed in front of every line (which library variant this is)")
     a = ap.parse_args()
     import torch
     from unclerenderer_amd import hostmath, synth
@@ -48,6 +51,8 @@ def main():
     hp = HotPath(0)
     W, H = a.width, a.height
     fc = hostmath.build_frame_constants("sponza", W, H)
+    if a.no_shadows:
+        fc.scene.ShadowStrength = 0.0
     asset_dir = Path(__file__).resolve().parent.parent / "tests" / "golden" / "assets"
     if (asset_dir / "output_pmrem.dds").exists():
         from unclerenderer_amd import assets
@@ -60,12 +65,21 @@ def main():
     modes = ["scene", "iid"] if a.gbuffer == "both" else [a.gbuffer]
     for mode in modes if not a.no_light else []:
         t0 = time.time()
-        if mode == "scene":
-            g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, W, H, 3)
-            shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+        cache = Path(a.cache) / f"g_{mode}_{W}x{H}.npz" if a.cache else None
+        if cache is not None and cache.exists():
+            z = np.load(cache)
+            g = synth.GBuffer(W, H, 0, H, z["A"], z["B"], z["C"], z["hdr"], z["depth"])
+            shadow = z["shadow"]
         else:
-            g = synth.gbuffer_iid(W, H, 3)
-            shadow = synth.shadow_map_noise(2048, 3)
+            if mode == "scene":
+                g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, W, H, 3)
+                shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+            else:
+                g = synth.gbuffer_iid(W, H, 3)
+                shadow = synth.shadow_map_noise(2048, 3)
+            if cache is not None:
+                cache.parent.mkdir(parents=True, exist_ok=True)
+                np.savez(cache, A=g.A, B=g.B, C=g.C, hdr=g.hdr, depth=g.depth, shadow=shadow)
         tables = hp.make_tables(to_device(shadow), d_env, 256, 9, to_device(lut))
         sets = [dict(A=to_device(g.A), B=to_device(g.B), C=to_device(g.C), D=to_device(g.depth), hdr=to_device(g.hdr)) for _ in range(a.ring)]
         n_sky = int((g.depth == 0).sum()); n_geo = g.depth.size - n_sky
@@ -75,7 +89,7 @@ def main():
             s = sets[k % a.ring]
             hp.deferred_lighting_sky(fc.scene, fc.sky, s["A"], s["B"], s["C"], s["D"], tables, s["hdr"], W, H)
         med, mn = time_events(torch, fused, a.iters)
-        print(f"[{mode}] fused lighting+sky {W}x{H}: median {med:.1f} us  min {mn:.1f} us  {nbytes / med / 1e3:.0f} GB/s  "
+        print(f"{a.tag}[{mode}] fused lighting+sky {W}x{H}: median {med:.1f} us  min {mn:.1f} us  {nbytes / med / 1e3:.0f} GB/s  "
               f"{100 * nbytes / med / 1e3 / 8000:.1f}% of 8 TB/s  {W * H / med:.0f} Mpx/s  (gen {time.time() - t0:.1f}s, sky {n_sky / g.depth.size:.3f})", flush=True)
     if a.hzb:
         for (w, h) in [(1920, 1080), (3840, 2160), (7680, 4320)]:

@@ -103,7 +103,9 @@ uint16_t finish_unquantize(int v, bool is_signed)
 }
 
 // Decode one 16-byte block into 16 texels (row-major 4x4), alpha = 1.0. Returns false on a reserved mode.
-bool decode_bc6h_block(const uint8_t* block, bool is_signed, ur_half4 out[16])
+// endpoints_out (nullable): the unquantized endpoints r[4], g[4], b[4] (subset 0: [0],[1]; subset 1: [2],[3]); mode_out
+// (nullable): the mode number 1..14 (0 = reserved).
+bool decode_bc6h_block(const uint8_t* block, bool is_signed, ur_half4 out[16], int32_t* endpoints_out = nullptr, int* mode_out = nullptr)
 {
     BitReader br;
     std::memcpy(&br.lo, block, 8);
@@ -203,7 +205,13 @@ bool decode_bc6h_block(const uint8_t* block, bool is_signed, ur_half4 out[16])
         break;
     default: // reserved modes decode to zero (D3D behaviour)
         for (int i = 0; i < 16; ++i) out[i] = {0, 0, 0, 0x3C00};
+        if (mode_out) *mode_out = 0;
+        if (endpoints_out) std::memset(endpoints_out, 0, 12 * sizeof(int32_t));
         return false;
+    }
+    if (mode_out) {
+        static const uint8_t kModeNumber[32] = {1, 2, 3, 11, 0, 0, 4, 12, 0, 0, 5, 13, 0, 0, 6, 14, 0, 0, 7, 0, 0, 0, 8, 0, 0, 0, 9, 0, 0, 0, 10, 0};
+        *mode_out = kModeNumber[mode];
     }
 #undef RW
 #undef GW
@@ -241,6 +249,8 @@ bool decode_bc6h_block(const uint8_t* block, bool is_signed, ur_half4 out[16])
         if (!is_signed) e[0] &= (1 << mi.wbits) - 1;
         for (int i = 0; i < num_ep; ++i) e[i] = unquantize(e[i], mi.wbits, is_signed);
     }
+    if (endpoints_out)
+        for (int i = 0; i < 4; ++i) { endpoints_out[i] = r[i]; endpoints_out[4 + i] = g[i]; endpoints_out[8 + i] = b[i]; }
     const int ibits = mi.regions == 2 ? 3 : 4;
     const int* weights = mi.regions == 2 ? kWeights3 : kWeights4;
     for (int i = 0; i < 16; ++i) {
@@ -365,5 +375,13 @@ int ur_dds_copy_rg16(const void* file, size_t size, const ur_dds_info* d, uint16
 }
 
 int ur_bc6h_decode_block(const uint8_t block[16], int is_signed, ur_half4 out[16]) { return decode_bc6h_block(block, is_signed != 0, out) ? 1 : 0; }
+
+int ur_bc6h_block_endpoints(const uint8_t block[16], int is_signed, int32_t endpoints[12])
+{
+    ur_half4 texels[16];
+    int mode = 0;
+    decode_bc6h_block(block, is_signed != 0, texels, endpoints, &mode);
+    return mode;
+}
 
 } // extern "C"

@@ -669,9 +669,35 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 #define UR_STAMP(var) do { } while (0)
 #endif
 
+// Diagnostic builds only (tools/build_variants.py): UR_ABLATE removes one part of the loop so that its cost can be read off
+// a timing; the output of such a build is wrong by construction. 1: no cube filter (loads kept), 2: no cube lookups at all,
+// 4: no irradiance lookup, 8: no BRDF LUT lookup, 16: no shading at all (DMA in, store out), 32: sRGB decode without the table.
+#ifndef UR_ABLATE
+#define UR_ABLATE 0
+#endif
+// HDR store flavour: 0 plain, 1 nontemporal (nt), 2 write-through (sc1): what the launch leaves dirty in L2 is written back
+// at its end, on the critical path of the next launch.
+#ifndef UR_HDR_STORE
+#define UR_HDR_STORE 0
+#endif
+__device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint32_t lo, uint32_t hi)
+{
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = {lo, hi};
+    UR_GLOBAL u32x2_t* dst = reinterpret_cast<UR_GLOBAL u32x2_t*>((UR_GLOBAL char*)base + byte_offset);
+#if UR_HDR_STORE == 1
+    __builtin_nontemporal_store(v, dst);
+#elif UR_HDR_STORE == 2
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(byte_offset), "v"(v), "s"(base) : "memory");
+#else
+    *dst = v;
+#endif
+}
+
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p, ur::HzbTail hzbTail)
 {
+    constexpr int kAbl = UR_ABLATE;
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the per-tile kernel");
 #ifdef UR_STAMPS
     unsigned long long t0 = 0, r0 = 0, tL = 0, tX = 0, r1 = 0, tP1 = 0, tP2 = 0, tP3 = 0, tP4 = 0;
@@ -834,7 +860,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             }
         }
         float outw = 1.0f;
-        if (__any(!sky)) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
+        if (!(kAbl & 16) && __any(!sky)) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
             // ---- decode; every vector in WORLD space (the view matrix is rigid): the camera ray through the pixel is affine in
             //      ndc, the normal is rotated once, and the reflection vector needs no rotation of its own ----------------------
             const float nx = h2f_lo(ga.x), ny = h2f_hi(ga.x), nz = h2f_lo(ga.y), wv = h2f_hi(ga.y);
@@ -865,8 +891,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const float uR = fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
             const float vR = fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
             const void* env = p.hot.env;
-            u32x4_t p0a, p0b, p1a, p1b;
-            float fx0, fy0, fx1, fy1;
+            u32x4_t p0a = {0, 0, 0, 0}, p0b = p0a, p1a = p0a, p1b = p0a;
+            float fx0 = uR, fy0 = vR, fx1 = faceR, fy1 = fl;
+            if (!(kAbl & 2)) {
             {
                 const float x = fmaf(uR, e0.x, 0.5f), y = fmaf(vR, e0.x, 0.5f); // bordered coordinates in [0.5, N + 0.5]
                 const float i0 = floorf(x), j0 = floorf(y);
@@ -882,6 +909,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 8u;
                 p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB1));
+            }
             }
             const F3 Nw = N;
             const float faceN = __builtin_amdgcn_cubeid(Nw.x, Nw.y, Nw.z);
@@ -924,10 +952,11 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
             // table byte offsets straight from the packed texel: (c << 2) & 0x3FC, (c >> 6) & 0x3FC, (c >> 14) & 0x3FC
             const unsigned char* srgbB = reinterpret_cast<const unsigned char*>(srgb);
-            const F3 albedo = f3(*reinterpret_cast<const float*>(srgbB + ((gc << 2) & 0x3FCu)), *reinterpret_cast<const float*>(srgbB + ((gc >> 6) & 0x3FCu)),
-                                 *reinterpret_cast<const float*>(srgbB + ((gc >> 14) & 0x3FCu)));
-            float ba, bb;
-            {
+            const F3 albedo = (kAbl & 32) ? f3((float)(gc & 0xFFu) * (1.0f / 255.0f), (float)((gc >> 8) & 0xFFu) * (1.0f / 255.0f), (float)((gc >> 16) & 0xFFu) * (1.0f / 255.0f))
+                                          : f3(*reinterpret_cast<const float*>(srgbB + ((gc << 2) & 0x3FCu)), *reinterpret_cast<const float*>(srgbB + ((gc >> 6) & 0x3FCu)),
+                                               *reinterpret_cast<const float*>(srgbB + ((gc >> 14) & 0x3FCu)));
+            float ba = NdotV, bb = roughness;
+            if (!(kAbl & 8)) {
                 // bordered coordinates: x in [0.5, W + 0.5] (NdotV is saturated), y clamped likewise (roughness is not)
                 const float x = fmaf(NdotV, (float)kLutW, 0.5f);
                 const float y = __builtin_amdgcn_fmed3f(fmaf(roughness, (float)kLutH, 0.5f), 0.5f, (float)kLutH + 0.5f);
@@ -940,8 +969,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 ba = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
                 bb = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
             }
-            F3 irradiance = f3(0.0f, 0.0f, 0.0f);
-            if (IRR_LDS) {
+            F3 irradiance = (kAbl & 4) ? f3(uN, vN, faceN) : f3(0.0f, 0.0f, 0.0f);
+            if (IRR_LDS && !(kAbl & 4)) {
                 const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
                 const float fx = x - i0, fy = y - j0;
@@ -1025,7 +1054,11 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 float a10 = a0 * fx0, a00 = a0 - a10, a11 = a1 * fx0, a01 = a1 - a11;
                 float b10 = b0 * fx1, b00 = b0 - b10, b11 = b1 * fx1, b01 = b1 - b11;
                 asm volatile("" : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11));
-                float x = mul_lo(p0a.x, a00), y = mul_hi(p0a.x, a00), z = mul_lo(p0a.y, a00);
+                float x, y, z;
+                if (kAbl & 3) {
+                    x = h2f_lo(p0a.x) + h2f_lo(p0b.x); y = h2f_lo(p1a.x) + h2f_lo(p1b.x); z = fx0 + fy0 + fx1 + fy1;
+                } else {
+                x = mul_lo(p0a.x, a00); y = mul_hi(p0a.x, a00); z = mul_lo(p0a.y, a00);
                 x = mix_lo(x, p0a.z, a10); y = mix_hi(y, p0a.z, a10); z = mix_lo(z, p0a.w, a10);
                 x = mix_lo(x, p0b.x, a01); y = mix_hi(y, p0b.x, a01); z = mix_lo(z, p0b.y, a01);
                 x = mix_lo(x, p0b.z, a11); y = mix_hi(y, p0b.z, a11); z = mix_lo(z, p0b.w, a11);
@@ -1033,6 +1066,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 x = mix_lo(x, p1a.z, b10); y = mix_hi(y, p1a.z, b10); z = mix_lo(z, p1a.w, b10);
                 x = mix_lo(x, p1b.x, b01); y = mix_hi(y, p1b.x, b01); z = mix_lo(z, p1b.y, b01);
                 x = mix_lo(x, p1b.z, b11); y = mix_hi(y, p1b.z, b11); z = mix_lo(z, p1b.w, b11);
+                }
                 prefiltered = f3(x, y, z);
                 if (!IRR_LDS) {
                     CubeTaps t;
@@ -1069,7 +1103,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         if (ty * 4u + row < p.hot.rows) { // false only in the rows a partial bottom tile hangs over the band
             half4_t o;
             o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z; o.w = (_Float16)outw;
-            st<half4_t>(p.hot.hdr, ((ty * 4u) * p.hot.W + tx * 16u) * 8u + laneHdr, o);
+            uint2 ob;
+            __builtin_memcpy(&ob, &o, 8);
+            store_hdr(p.hot.hdr, ((ty * 4u) * p.hot.W + tx * 16u) * 8u + laneHdr, ob.x, ob.y);
         }
 #ifdef UR_STAMPS
         UR_STAMP(tF);

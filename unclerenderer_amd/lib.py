@@ -140,6 +140,7 @@ SIGNATURES = {
     "ur_dds_decode_rgba16f": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo), _VP, C.POINTER(_U32)]),
     "ur_dds_copy_rg16": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo), _VP]),
     "ur_bc6h_decode_block": (C.c_int, [_VP, C.c_int, _VP]),
+    "ur_bc6h_block_endpoints": (C.c_int, [_VP, C.c_int, _VP]),
     # ur_scene.h
     "ur_scene_model_count": (C.c_int, [C.c_char_p]),
     "ur_scene_model_path": (C.c_int, [C.c_char_p, _U32, C.c_char_p, _U32]),
