@@ -129,10 +129,13 @@ int ur_reserve(ur_ctx* ctx, uint32_t max_instances);
  * DeferredRenderer.cpp:1046-1207 builds the HZB, :1997-2005 lights). The last launch of ur_build_hzb is ONE workgroup
  * (the mips that fit LDS): ~5 us during which the rest of the chip idles. With ur_defer_hzb_tail(ctx, 1) that workgroup
  * is held back and rides along with the next ur_deferred_lighting / ur_deferred_lighting_sky launch on the same context
- * as an extra workgroup (when that launch uses the streaming kernel; the HZB is complete when that launch is). Anything
- * else that reads or rewrites the HZB through this context (ur_cull_indirect_args*, ur_build_hzb), ur_flush(),
- * ur_defer_hzb_tail(ctx, 0) and ur_destroy() launch a held-back tail on its own first. A caller that reads the HZB by
- * other means (its own kernels, a copy) calls ur_flush() before. Off by default. */
+ * as an extra workgroup when that launch uses the streaming kernel, and goes out on its own in front of a launch that uses
+ * the per-tile kernel: either way the HZB is complete when that Lighting launch is. Anything else that reads or rewrites
+ * the HZB through this context (ur_cull_indirect_args*, ur_build_hzb), ur_flush() and ur_defer_hzb_tail(ctx, 0) launch a
+ * held-back tail on its own first. ur_destroy() DISCARDS it (the HZB buffer may already be gone). While a tail is held
+ * back, ur_build_hzb has returned UR_OK with the levels of the tail still unwritten: a caller that reads the HZB by other
+ * means (its own kernels, a copy, another context or stream) calls ur_flush() first, and keeps the HZB buffer alive until
+ * then. Off by default. */
 int ur_defer_hzb_tail(ur_ctx* ctx, int enable);
 int ur_flush(ur_ctx* ctx);
 const char* ur_last_error(void);
@@ -148,7 +151,8 @@ uint32_t ur_hzb_layout(uint32_t src_w, uint32_t src_h, ur_mip_desc* mips /*host,
 
 /* depth: device, src_w*src_h floats (the depth buffer as the SRV sees it: reverse-Z in [0,1]).
  * hzb_base: device, laid out by `mips` (host). Builds every mip; values are bit-identical to the
- * reference's dispatch chain of <=4 mips per dispatch, including its out-of-range fill quirks. */
+ * reference's dispatch chain of <=4 mips per dispatch, including its out-of-range fill quirks.
+ * With ur_defer_hzb_tail(ctx, 1) the chain is complete only after ur_flush() or the next Lighting launch (see there). */
 int ur_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base,
                  const ur_mip_desc* mips, uint32_t mip_count);
 
@@ -236,6 +240,10 @@ int ur_temporal_aa(ur_ctx* ctx, const ur_half4* current_frame, const ur_half4* h
  * rows [r*h/n, (r+1)*h/n). In-place ncclAllGather on the ctx stream. Requires n | h. */
 int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, uint32_t h,
                       uint32_t n_ranks, uint32_t rank);
+/* The same for any row-major image of `row_bytes` per row — the tonemapped R8G8B8A8 band (ur_tonemap ahead of the gather:
+ * 4 B/pixel over xGMI instead of 8; SURVEY.md §8f-1, Shaders/Tonemap.hlsl:57-79). */
+int ur_allgather_rows_bytes(ur_ctx* ctx, void* comm, void* image, uint32_t row_bytes, uint32_t h, uint32_t n_ranks,
+                            uint32_t rank);
 
 #ifdef __cplusplus
 }

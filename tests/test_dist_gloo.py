@@ -40,6 +40,13 @@ def _worker(rank, world, port, w, h, n_inst, out_dir):
         assert work is not None
         work.wait()
         assert torch.equal(hdr_async, hdr_full)
+        # Tonemap ahead of the gather (bench.py --gather-ldr): the band is tonemapped where it was shaded and the 4-byte
+        # pixels travel instead of the 8-byte ones
+        ldr_band = o.tonemap(band, exposure=0.9, gamma=2.2)
+        ldr_full = torch.zeros((h, w), dtype=torch.int32)
+        work = urdist.allgather_rows(ldr_full, torch.from_numpy(ldr_band.view(np.int32)), async_op=True)
+        work.wait()
+        assert ldr_full.element_size() * ldr_full[0].numel() * 2 == hdr_full.element_size() * hdr_full[0].numel()  # half the bytes per row
         # cull: instance ranges + replicated HZB
         depth_full = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 17).depth
         mips, total = o.hzb_layout(w, h)
@@ -50,7 +57,7 @@ def _worker(rank, world, port, w, h, n_inst, out_dir):
         _, _, vis, cnt = o.cull_indirect_args(consts, bounds, hzb, mips, synth.indirect_args_initial(i1 - i0), index_base=i0)
         pad = np.zeros(max(i1 - i0, 1), np.int32); pad[:cnt] = vis.view(np.int32)
         all_vis, total_cnt = urdist.allgather_visible(torch.from_numpy(pad), torch.tensor([cnt], dtype=torch.int32))
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), hdr=hdr_full.numpy(), vis=all_vis.numpy(), cnt=total_cnt)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), hdr=hdr_full.numpy(), ldr=ldr_full.numpy(), vis=all_vis.numpy(), cnt=total_cnt)
     finally:
         dist.destroy_process_group()
 
@@ -65,6 +72,7 @@ def test_two_ranks_reproduce_single_rank(tmp_path, oracle, urlib):
     shadow, env, lut = synth.shadow_map_noise(64, 17), synth.env_cube_procedural(8, 4), synth.brdf_lut_procedural(16, 8)
     lit = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 8, 4, lut, g.hdr, w, h)
     ref = oracle.sky_atmosphere(fc.sky, g.depth, lit, w, h)
+    ref_ldr = oracle.tonemap(ref, exposure=0.9, gamma=2.2)
     mips, total = oracle.hzb_layout(w, h)
     hzb = np.nan_to_num(oracle.build_hzb(g.depth, mips, total))
     bounds = synth.instances_random(n, 17, center=fc.camera_position, box=60.0)
@@ -74,6 +82,7 @@ def test_two_ranks_reproduce_single_rank(tmp_path, oracle, urlib):
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(d["hdr"].view(np.uint16), ref), f"rank {r}: gathered HDR differs from the single-rank frame"
+        assert np.array_equal(d["ldr"].view(np.uint32), ref_ldr), f"rank {r}: gathered tonemapped frame differs from tonemapping the single-rank frame"
         assert int(d["cnt"]) == ref_cnt and np.array_equal(d["vis"].view(np.uint32), ref_vis)
 
 

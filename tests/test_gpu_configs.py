@@ -1,0 +1,219 @@
+"""The BASELINE.json configurations at their full sizes, through the C-ABI, against the oracle (on bands) and through
+size-independent properties (band split == whole frame, every pixel finite, alpha bookkeeping):
+
+  C2  Sponza 1920x1080 DeferredLighting GGX+IBL (fused with Sky), shipped IBL tables, 2048^2 shadow map
+  C4  pica_pica 3840x2160 screen-tiled 8 ways (the camera / light of Assets/Scenes/pica_pica.json)
+  C5  1 M instance AABBs culled against the 12-mip HZB that ur_build_hzb makes from a 7680x4320 depth, and the 8K G-buffer lit
+plus the kernel instantiations no other test reaches: IRR_LDS = false (the irradiance mip is larger than 2x2, so it is
+gathered from memory instead of LDS) and the 12-waves-per-workgroup build (UR_LIGHTING_WPB=12, read once per process)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import hdr_mismatch
+
+pytestmark = pytest.mark.gpu
+ASSETS = Path(__file__).parent / "golden" / "assets"
+
+
+def _shipped_tables(hotpath, shadow):
+    from unclerenderer_amd import assets
+    from unclerenderer_amd.hotpath import to_device
+    env, base, mips, bad = assets.load_env_cube_dds(ASSETS / "output_pmrem.dds")
+    lut = assets.load_brdf_lut_dds(ASSETS / "PreintegratedGF.dds")
+    assert (base, mips, bad) == (256, 9, 0)
+    return env, lut, hotpath.make_tables(to_device(shadow), hotpath.stage_env_cube(env, base, mips), base, mips, to_device(lut))
+
+
+def _bands_equal_whole_and_oracle(hotpath, oracle, fc, g, shadow, env, lut, tables, w, h, n_bands, oracle_bands):
+    import torch
+    from unclerenderer_amd.hotpath import to_device
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+    whole = to_device(g.hdr)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, whole, w, h)
+    parts = to_device(g.hdr)
+    rows = h // n_bands
+    assert rows * n_bands == h
+    for r in range(n_bands):
+        sl = slice(r * rows, (r + 1) * rows)
+        hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA[sl], dB[sl], dC[sl], dD[sl], tables, parts[sl], w, h, r * rows, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, parts), f"{n_bands} row bands differ from the whole frame"
+    out = whole.cpu().numpy().view(np.float16).astype(np.float32)
+    assert np.isfinite(out).all(), "after the fused sky pass no pixel may be NaN/inf"
+    assert (out[..., 3][g.depth == 0] == 1.0).all() and (out[..., 3][g.depth > 0] == 2.0).all()
+    for r0, nr in oracle_bands:
+        sl = slice(r0, r0 + nr)
+        lit, frag = oracle.deferred_lighting(fc.scene, g.A[sl], g.B[sl], g.C[sl], shadow, env, 256, 9, lut, g.hdr[sl], w, h, r0, nr, want_fragile=True)
+        ref = oracle.sky_atmosphere(fc.sky, g.depth[sl], lit, w, h, r0, nr)
+        nbad, worst, _ = hdr_mismatch(whole[sl].cpu().numpy().view(np.uint16), ref, exclude=frag)
+        assert nbad == 0, f"rows {r0}..{r0 + nr}: {nbad} channel values beyond max(1e-3, 1 ulp fp16) (worst excess {worst})"
+        assert frag.mean() < 5e-3
+
+
+def test_c2_sponza_1080p_lighting(hotpath, oracle):
+    from unclerenderer_amd import hostmath, synth
+    w, h = 1920, 1080
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=2048, env_mip_count=9)
+    g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, synth.SEED_BASE + 2)
+    shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+    env, lut, tables = _shipped_tables(hotpath, shadow)
+    # 1080 rows = 8 bands of 135 (not a multiple of the 4-row tile: every band ends in a partial tile row)
+    _bands_equal_whole_and_oracle(hotpath, oracle, fc, g, shadow, env, lut, tables, w, h, 8, [(0, 32), (700, 32)])
+
+
+def test_c2_sponza_1080p_lighting_only_pass(hotpath, oracle):
+    """The same configuration as the reference records it: Lighting (additive, every pixel) then Sky, two launches."""
+    import torch
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import to_device
+    w, h = 1920, 1080
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=2048, env_mip_count=9)
+    g = synth.gbuffer_iid(w, h, synth.SEED_BASE + 2)  # SURVEY.md section 8d's generator
+    shadow = synth.shadow_map_noise(2048, synth.SEED_BASE + 2)
+    env, lut, tables = _shipped_tables(hotpath, shadow)
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+    two, fused = to_device(g.hdr), to_device(g.hdr)
+    hotpath.deferred_lighting(fc.scene, dA, dB, dC, tables, two, w, h)
+    hotpath.sky_atmosphere(fc.sky, dD, two, w, h)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, fused, w, h)
+    torch.cuda.synchronize()
+    assert torch.equal(two, fused), "fused launch == Lighting then Sky, bit for bit"
+    r0, nr = 512, 24
+    sl = slice(r0, r0 + nr)
+    lit, frag = oracle.deferred_lighting(fc.scene, g.A[sl], g.B[sl], g.C[sl], shadow, env, 256, 9, lut, g.hdr[sl], w, h, r0, nr, want_fragile=True)
+    ref = oracle.sky_atmosphere(fc.sky, g.depth[sl], lit, w, h, r0, nr)
+    nbad, worst, _ = hdr_mismatch(fused[sl].cpu().numpy().view(np.uint16), ref, exclude=frag)
+    assert nbad == 0, (nbad, worst)
+
+
+def test_c4_pica_pica_4k_eight_bands(hotpath, oracle):
+    from unclerenderer_amd import hostmath, synth
+    w, h = 3840, 2160
+    fc = hostmath.build_frame_constants("pica_pica", w, h, shadow_size=2048, env_mip_count=9)
+    assert tuple(np.round(fc.camera_position, 3)) == (-13.482, 20.457, -42.455)
+    g = synth.gbuffer_iid(w, h, synth.SEED_BASE + 4)
+    shadow = synth.shadow_map_noise(2048, synth.SEED_BASE + 4)
+    env, lut, tables = _shipped_tables(hotpath, shadow)
+    _bands_equal_whole_and_oracle(hotpath, oracle, fc, g, shadow, env, lut, tables, w, h, 8, [(270 * 3 - 16, 32), (2160 - 24, 24)])
+
+
+def test_c5_cull_1m_against_the_8k_hzb(hotpath, oracle):
+    """1 M instances against the chain ur_build_hzb produces from a 7680x4320 depth (12 mips, three launches): HZB bit-exact
+    against the oracle's chain, InstanceCount words / visible list / counters bit-exact against the oracle's cull of it."""
+    import torch
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    w, h, n = 7680, 4320, 1_000_000
+    fc = hostmath.build_frame_constants("sponza", w, h)
+    depth = synth.gbuffer_iid(w, h, synth.SEED_BASE + 5).depth
+    lay = HzbLayout(w, h)
+    assert lay.count == 12
+    hzb = torch.zeros(lay.total, device="cuda")
+    hotpath.build_hzb(to_device(depth), hzb, lay)
+    ref_hzb = np.nan_to_num(oracle.build_hzb(depth, lay.as_list(), lay.total))
+    got = hzb.cpu().numpy()
+    for (off, mw, mh) in lay.as_list():
+        assert np.array_equal(got[off:off + mw * mh].view(np.uint32), ref_hzb[off:off + mw * mh].view(np.uint32)), f"mip {mw}x{mh}"
+    bounds = synth.instances_random(n, synth.SEED_BASE + 5, center=fc.camera_position, box=400.0)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, n, True, lay.count, lay.width, lay.height, True)
+    args0 = synth.indirect_args_initial(n)
+    ref_args, ref_stats, ref_vis, ref_cnt = oracle.cull_indirect_args(consts, bounds, ref_hzb, lay.as_list(), args0)
+    d_args, d_stats = to_device(args0), torch.zeros(2, dtype=torch.int32, device="cuda")
+    d_vis, d_cnt = torch.full((n,), -1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    hotpath.cull_indirect_args(consts, to_device(bounds), hzb, lay, d_args, d_stats, d_vis, d_cnt)  # the HZB the GPU built
+    torch.cuda.synchronize()
+    assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args)
+    assert int(d_cnt.cpu()[0]) == ref_cnt and np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt], ref_vis)
+    assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats)
+    assert ref_cnt > 1000 and ref_stats[0] > 0 and ref_stats[1] > 0, "both rejection paths and the visible path are exercised"
+    assert np.all(np.diff(ref_vis.astype(np.int64)) > 0)
+
+
+def test_c5_8k_gbuffer_lighting(hotpath, oracle):
+    from unclerenderer_amd import hostmath, synth
+    w, h = 7680, 4320
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=2048, env_mip_count=9)
+    g = synth.gbuffer_iid(w, h, synth.SEED_BASE + 5)
+    shadow = synth.shadow_map_noise(2048, synth.SEED_BASE + 5)
+    env, lut, tables = _shipped_tables(hotpath, shadow)
+    _bands_equal_whole_and_oracle(hotpath, oracle, fc, g, shadow, env, lut, tables, w, h, 8, [(540 * 5 - 8, 16)])
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("shadows", [False, True])
+def test_irradiance_mip_gathered_from_memory(hotpath, oracle, fused, shadows):
+    """IRR_LDS = false: EnvMapMipCount - 1 lands on a mip larger than 2x2 (here 8x8), which does not fit the kernel's LDS
+    table: the irradiance taps are global gathers like the prefiltered ones."""
+    import torch
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import to_device
+    w, h = 320, 180
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=256, shadow_strength=1.0 if shadows else 0.0, env_mip_count=3)
+    assert fc.scene.EnvMapMipCount == 3.0  # level 2 of a 32^2 cube = 8x8
+    env, lut, shadow = synth.env_cube_procedural(32, 6), synth.brdf_lut_procedural(128, 32), synth.shadow_map_noise(256, 41)
+    tables = hotpath.make_tables(to_device(shadow) if shadows else None, hotpath.stage_env_cube(env, 32, 6), 32, 6, to_device(lut))
+    for g in (synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 41), synth.gbuffer_iid(w, h, 41)):
+        lit, frag = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow if shadows else None, env, 32, 6, lut, g.hdr, w, h, want_fragile=True)
+        ref = oracle.sky_atmosphere(fc.sky, g.depth, lit, w, h) if fused else lit
+        hdr = to_device(g.hdr)
+        if fused:
+            hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, hdr, w, h)
+        else:
+            hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, hdr, w, h)
+        torch.cuda.synchronize()
+        nbad, worst, _ = hdr_mismatch(hdr.cpu().numpy().view(np.uint16), ref, exclude=frag)
+        assert nbad == 0, (nbad, worst)
+
+
+_CHILD = """
+import numpy as np, sys, torch
+sys.path.insert(0, %(root)r)
+from tests.test_gpu_parity import _lighting_inputs, _device_tables
+from unclerenderer_amd import hostmath, synth
+from unclerenderer_amd.hotpath import HotPath, to_device
+hp = HotPath(0)
+out = {}
+for name, (w, h, mips) in {"lds": (320, 180, 6.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
+    fc, g, shadow, env, lut = _lighting_inputs('sponza', w, h, seed=33, mode='scene')
+    fc.scene.EnvMapMipCount = mips
+    tables = _device_tables(hp, shadow, env, lut)
+    for fused in (0, 1):
+        hdr = to_device(g.hdr)
+        if fused:
+            hp.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, hdr, w, h)
+        else:
+            hp.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, hdr, w, h)
+        torch.cuda.synchronize()
+        out[f"{name}{fused}"] = hdr.cpu().numpy().view(np.uint16)
+np.savez(%(dst)r, **out)
+"""
+
+
+def test_twelve_wave_workgroups_give_the_same_bits(hotpath, tmp_path):
+    """UR_LIGHTING_WPB=12 (3 waves per SIMD) runs the same arithmetic on a different work split: bit-identical output to the
+    default 16-wave build, for the LDS and the gathered irradiance, fused and not, and with partial tile rows."""
+    import torch
+    from tests.test_gpu_parity import _device_tables, _lighting_inputs
+    from unclerenderer_amd.hotpath import to_device
+    dst = tmp_path / "wpb12.npz"
+    code = _CHILD % dict(root=str(Path(__file__).resolve().parent.parent), dst=str(dst))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UR_LIGHTING_WPB="12"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    child = np.load(dst)
+    for name, (w, h, mips) in {"lds": (320, 180, 6.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
+        fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=33, mode="scene")
+        fc.scene.EnvMapMipCount = mips
+        tables = _device_tables(hotpath, shadow, env, lut)
+        for fused in (0, 1):
+            hdr = to_device(g.hdr)
+            if fused:
+                hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, hdr, w, h)
+            else:
+                hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, hdr, w, h)
+            torch.cuda.synchronize()
+            assert np.array_equal(hdr.cpu().numpy().view(np.uint16), child[f"{name}{fused}"]), (name, fused)

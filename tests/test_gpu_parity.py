@@ -291,16 +291,21 @@ def test_lighting_shadow_border_and_outside(hotpath, oracle):
     torch.cuda.synchronize()
     nbad, worst, _ = hdr_mismatch(d.cpu().numpy().view(np.uint16), ref_l, exclude=fragile)
     assert nbad == 0, (nbad, worst)
+    # an 8x8 map stretched over the whole view: a texel edge (where the PCF compare may flip within 1e-5) crosses most of the
+    # 192x108 pixels' footprints, so the flagged share is large HERE; the full-size configurations flag < 0.5 % (test_gpu_configs)
     assert fragile.mean() < 0.05
+    assert (~fragile.astype(bool)).sum() > 0.9 * w * h
 
 
-def test_streaming_and_per_tile_kernels_agree(hotpath, tmp_path):
+def test_streaming_and_per_tile_kernels_agree(hotpath, oracle, tmp_path):
     """The two lighting kernels are independent implementations of the same pass (the per-tile one serves sky-only launches
-    and the configurations the streaming kernel declines): on the same inputs they agree within the HDR tolerance.
+    and the configurations the streaming kernel declines): on the same inputs EACH is within the HDR tolerance of the
+    oracle on every pixel that is not shadow-compare fragile, hence they are within twice that of each other.
     The per-tile kernel runs in a child process (UR_LIGHTING_STREAM is read once per process)."""
     import os
     import subprocess
     import sys
+    from tests.util import fp16_ulp, half_to_f32
     from unclerenderer_amd.hotpath import to_device
     torch = _torch()
     w, h = 320, 180
@@ -327,8 +332,15 @@ def test_streaming_and_per_tile_kernels_agree(hotpath, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UR_LIGHTING_STREAM="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     tile_bits = np.load(child)
-    nbad, worst, _ = hdr_mismatch(stream_bits, tile_bits)
-    assert nbad <= 8, f"{nbad} channel values differ beyond tolerance between the two kernels (worst excess {worst})"
+    lit, frag = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 32, 6, lut, g.hdr, w, h, want_fragile=True)
+    ref = oracle.sky_atmosphere(fc.sky, g.depth, lit, w, h)
+    for name, bits in (("streaming", stream_bits), ("per-tile", tile_bits)):
+        nbad, worst, _ = hdr_mismatch(bits, ref, exclude=frag)
+        assert nbad == 0, f"{name} kernel: {nbad} channel values beyond tolerance of the oracle (worst excess {worst})"
+    a, b, r32 = half_to_f32(stream_bits), half_to_f32(tile_bits), half_to_f32(ref)
+    keep = ~frag.astype(bool)
+    assert (np.abs(a - b)[keep] <= 2.0 * np.maximum(np.float32(1e-3), fp16_ulp(r32))[keep]).all()
+    assert frag.mean() < 5e-3
 
 
 def test_row_bands_equal_whole_frame(hotpath):

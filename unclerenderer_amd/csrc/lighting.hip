@@ -1174,10 +1174,12 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
 #endif
     constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
     auto kern = lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB>;
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
+    // MaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: one flag per instantiation and device
+    static bool attr_set[64] = {};
+    const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : -1;
+    if (dev < 0 || !attr_set[dev]) {
         UR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
     }
     StreamHot& h = p.hot;
     h.tilesX = p.W / 16u;
@@ -1185,15 +1187,18 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     // A deferred HZB tail (ur_defer_hzb_tail) rides along as one extra 1024-thread workgroup on a CU of its own: the
     // lighting workgroups give up one CU (0.4 % of their throughput) and the frame saves a ~5 us single-workgroup launch.
     ur::HzbTail tail{};
-    const bool carry_tail = ctx->hzb_tail_pending && WPB == 16 && ctx->cu_count >= 16;
+    // UR_LIGHTING_LEAVE_CUS = n leaves n CUs to kernels of other streams (the graph's async-compute passes): the persistent
+    // workgroups otherwise fill every CU's register file and nothing runs beside them. Never below one lighting workgroup
+    // (a CPX partition reports 32 CUs), and the tail is carried only when that still leaves the lighting a CU of its own.
+    static const int leave_env = std::min(std::max(env_int("UR_LIGHTING_LEAVE_CUS", 0), 0), 128);
+    const int cus = std::max(ctx->cu_count, 1);
+    const int leave_cus = std::min(leave_env, cus - 1);
+    const bool carry_tail = ctx->hzb_tail_pending && WPB == 16 && cus >= 16 && cus - leave_cus >= 2;
     if (carry_tail) {
         tail = ctx->pending_tail;
         ctx->hzb_tail_pending = false;
     }
-    // UR_LIGHTING_LEAVE_CUS = n leaves n CUs to kernels of other streams (the graph's async-compute passes): the persistent
-    // workgroups otherwise fill every CU's register file and nothing runs beside them
-    static const int leave_cus = std::min(std::max(env_int("UR_LIGHTING_LEAVE_CUS", 0), 0), 128);
-    const uint32_t groups = std::min<uint32_t>((uint32_t)ctx->cu_count - (carry_tail ? 1u : 0u) - (uint32_t)leave_cus, (h.numTiles + WPB - 1) / WPB);
+    const uint32_t groups = std::min<uint32_t>((uint32_t)std::max(1, cus - (carry_tail ? 1 : 0) - leave_cus), (h.numTiles + WPB - 1) / WPB);
     h.groups = groups;
     // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
@@ -1413,6 +1418,10 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         }
     }
     if (!streamed) {
+        // the per-tile kernel cannot carry a held-back HZB tail: it goes out on its own, in front (ur_defer_hzb_tail's contract:
+        // every Lighting launch on the context completes the chain)
+        const int frc = flush_hzb_tail(ctx);
+        if (frc != UR_OK) return frc;
         switch (mode) {
         case UR_MODE_LIGHTING:
             if (shadows) launch_tiled<UR_MODE_LIGHTING, true>(ctx, p); else launch_tiled<UR_MODE_LIGHTING, false>(ctx, p);

@@ -78,6 +78,23 @@ bool valid_hzb_chain(uint32_t src_w, uint32_t src_h, const ur_mip_desc* mips, ui
     return true;
 }
 
+// the levels below mips[0] halve by FLOOR (CreateHZBResources, DeferredRenderer.cpp:2801-2835); every level lies inside the
+// allocation the layout describes (offsets ascending, no overlap)
+bool valid_hzb_chain_below_mip0(const ur_mip_desc* mips, uint32_t mip_count)
+{
+    if (!mips || mip_count == 0 || mip_count > UR_MAX_HZB_MIPS) return false;
+    uint32_t w = mips[0].width, h = mips[0].height;
+    if (w == 0 || h == 0) return false;
+    uint64_t end = 0;
+    for (uint32_t m = 0; m < mip_count; ++m) {
+        if (mips[m].width != w || mips[m].height != h) return false;
+        if (m != 0 && mips[m].offset < end) return false;
+        end = (uint64_t)mips[m].offset + (uint64_t)w * h;
+        w = w / 2 ? w / 2 : 1; h = h / 2 ? h / 2 : 1;
+    }
+    return true;
+}
+
 typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
 
 } // namespace
@@ -125,7 +142,9 @@ ur_ctx* ur_create(int device, void* stream)
 void ur_destroy(ur_ctx* ctx)
 {
     if (!ctx) return;
-    (void)ur::flush_hzb_tail(ctx);
+    // A held-back HZB tail is DISCARDED, not launched: the caller may already have freed the HZB buffer it points into (the
+    // chain is complete only after ur_flush or a streaming Lighting launch — see ur_build_hzb in the header).
+    ctx->hzb_tail_pending = false;
     if (ctx->srgb_table) (void)hipFree(ctx->srgb_table);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
@@ -200,6 +219,8 @@ int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_fl
     if (n != 0 && hzb_on != 0 && constants[43] != 0 && constants[44] != 0 && mipc != 0) {
         if (!hzb_base || !mips || mipc > UR_MAX_HZB_MIPS) { set_error("ur_cull_indirect_args: HZB enabled but hzb/mips missing"); return UR_EINVAL; }
         if (mips[0].width != constants[43] || mips[0].height != constants[44]) { set_error("ur_cull_indirect_args: HZBWidth/Height do not match mips[0]"); return UR_EINVAL; }
+        // the kernel indexes hzb + mips[level].offset with pitch mips[level].width for every level up to HZBMipCount - 1
+        if (!valid_hzb_chain_below_mip0(mips, mipc)) { set_error("ur_cull_indirect_args: mips[1..%u] do not halve from mips[0] / overlap", mipc - 1); return UR_EINVAL; }
     }
     return ur::launch_cull(ctx, constants, bounds, hzb_base, mips, indirect_args, stats2, visible_idx, visible_count, index_base);
 }
@@ -286,14 +307,14 @@ int ur_deferred_lighting_sky(ur_ctx* ctx, const ur_scene_constants* scene, const
     return ur::launch_lighting(ctx, scene, sky, a, b, c, depth, tables, hdr, w, h, row0, rows, ur::UR_MODE_FUSED);
 }
 
-int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, uint32_t h, uint32_t n_ranks, uint32_t rank)
+int ur_allgather_rows_bytes(ur_ctx* ctx, void* comm, void* image, uint32_t row_bytes, uint32_t h, uint32_t n_ranks, uint32_t rank)
 {
-    if (!ctx || !comm || !hdr_full || n_ranks == 0 || rank >= n_ranks || h % n_ranks != 0) {
-        set_error("ur_allgather_rows: bad argument (h=%u ranks=%u rank=%u)", h, n_ranks, rank);
+    if (!ctx || !comm || !image || row_bytes == 0 || h == 0 || n_ranks == 0 || rank >= n_ranks || h % n_ranks != 0) {
+        set_error("ur_allgather_rows: bad argument (row_bytes=%u h=%u ranks=%u rank=%u)", row_bytes, h, n_ranks, rank);
         return UR_EINVAL;
     }
-    // RCCL is resolved at run time from whatever copy the host process already loaded (torch ships its own), so the
-    // library has no link-time dependency on a second RCCL.
+    // RCCL is resolved at run time from whatever copy the host process already loaded globally (the communicator must
+    // come from the same copy), falling back to the system's librccl: the library has no link-time dependency on RCCL.
     static nccl_allgather_fn fn = nullptr;
     if (!fn) {
         fn = reinterpret_cast<nccl_allgather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
@@ -304,11 +325,17 @@ int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, u
         }
         if (!fn) { set_error("ur_allgather_rows: ncclAllGather not found"); return UR_EUNSUPPORTED; }
     }
-    const size_t band_bytes = (size_t)w * (h / n_ranks) * sizeof(ur_half4);
-    const char* send = reinterpret_cast<const char*>(hdr_full) + band_bytes * rank;
-    const int rc = fn(send, hdr_full, band_bytes, /*ncclInt8*/ 0, comm, ctx->stream);
+    const size_t band_bytes = (size_t)row_bytes * (h / n_ranks);
+    const char* send = reinterpret_cast<const char*>(image) + band_bytes * rank;
+    const int rc = fn(send, image, band_bytes, /*ncclInt8*/ 0, comm, ctx->stream);
     if (rc != 0) { set_error("ncclAllGather failed (%d)", rc); return UR_EHIP; }
     return UR_OK;
+}
+
+int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, uint32_t h, uint32_t n_ranks, uint32_t rank)
+{
+    if ((uint64_t)w * sizeof(ur_half4) > 0xFFFFFFFFull) { set_error("ur_allgather_rows: row of %u pixels is too wide", w); return UR_EINVAL; }
+    return ur_allgather_rows_bytes(ctx, comm, hdr_full, w * (uint32_t)sizeof(ur_half4), h, n_ranks, rank);
 }
 
 } // extern "C"

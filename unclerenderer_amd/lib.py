@@ -134,6 +134,7 @@ SIGNATURES = {
     "ur_tonemap": (C.c_int, [_VP, C.POINTER(TonemapConstants), _VP, _VP, _VP, _U32, _U32]),
     "ur_temporal_aa": (C.c_int, [_VP, _VP, _VP, _VP, _F, _U32, _U32, _U32, _U32, _U32]),
     "ur_allgather_rows": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
+    "ur_allgather_rows_bytes": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
     # ur_assets.h
     "ur_dds_parse": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo)]),
     "ur_dds_texel_count": (C.c_size_t, [C.POINTER(DdsInfo)]),
