@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--async-compute", action="store_true",
                     help="put the visibility passes on the graph's async-compute stream. Off by default: the streaming lighting kernel "
                          "keeps every CU's register file full, so the passes no longer run beside it (measured: same frame time)")
+    ap.add_argument("--hzb-launch", choices=["ride", "tail-rides", "separate"], default="ride",
+                    help="ride: the whole Build HZB chain rides along with the Lighting launch (two launches per frame); tail-rides: only its "
+                         "single-workgroup tail does (three launches); separate: Build HZB is launches of its own (four)")
     ap.add_argument("--separate-hzb-tail", action="store_true",
                     help="launch the single-workgroup tail of Build HZB on its own (three visibility launches per frame) instead of "
                          "letting it ride along with the Lighting launch as an extra workgroup")
@@ -192,8 +195,12 @@ def main():
     frame = Frame(hp, frames_in_flight=3, rank=rank, world_size=N)
     hzb = torch.zeros(lay.total, dtype=torch.float32, device=f"cuda:{dev}")
     flags = urlib.UR_FRAME_DEFAULT | urlib.UR_FRAME_FUSE_LIGHTING_SKY
-    if not args.separate_hzb_tail:
-        flags |= urlib.UR_FRAME_HZB_TAIL_WITH_LIGHTING  # (ignored with --async-compute)
+    if args.separate_hzb_tail:
+        args.hzb_launch = "separate"
+    if args.hzb_launch == "ride":
+        flags |= urlib.UR_FRAME_HZB_WITH_LIGHTING  # (ignored with --async-compute)
+    elif args.hzb_launch == "tail-rides":
+        flags |= urlib.UR_FRAME_HZB_TAIL_WITH_LIGHTING
     if args.gather_ldr:
         flags |= urlib.UR_FRAME_TONEMAP
     if args.async_compute:
@@ -278,7 +285,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    light_ms = frame.lighting_times_ms().astype(np.float64)  # inside the timed region
+    light_ms, record_ms = (a.astype(np.float64) for a in frame.lighting_times_and_record_cost_ms())  # inside the timed region
     # the same kernel alone on the stream (no concurrent visibility passes), for reference
     evs = []
     for k in range(min(args.steps, 100)):
@@ -291,13 +298,18 @@ def main():
     torch.cuda.synchronize()
     alone_ms = np.array([a.elapsed_time(b) for a, b in evs], dtype=np.float64)
     if light_ms.size == 0:
-        light_ms = alone_ms
+        light_ms, record_ms = alone_ms, np.zeros_like(alone_ms)
     n_sky = int((g.depth == 0).sum())
     n_geo = g.depth.size - n_sky
     # algorithmic bytes of one fused launch on this rank: geometry pixels read A 8 + B 8 + C 4 + depth 4 + HDR 8 and write
     # HDR 8 (= 40 B); sky pixels read depth 4 and write HDR 8 (= 12 B). Side tables are cache-resident and excluded.
     light_bytes = 40 * n_geo + 12 * n_sky
-    light_avg_s = float(light_ms.mean()) * 1e-3
+    # An event pair brackets [record, launch, record]: the record in front of the launch sits inside the bracket. Its cost is
+    # measured in the same frames by a third event recorded right behind the pair (nothing in between) and taken out; the
+    # result is what rocprofv3's kernel trace reports for the dispatch (profiles/: same command). Raw values are reported too.
+    bracket_avg_s = float(light_ms.mean()) * 1e-3
+    record_avg_s = float(record_ms.mean()) * 1e-3
+    light_avg_s = bracket_avg_s - record_avg_s
     achieved = light_bytes / light_avg_s / 1e9
 
     result = {
@@ -324,12 +336,14 @@ def main():
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
-            "async_compute": args.async_compute, "hip_graph": bool(args.graph), "hzb_tail": "separate launch" if (args.separate_hzb_tail or args.async_compute) else "extra workgroup of the Lighting launch", "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
+            "async_compute": args.async_compute, "hip_graph": bool(args.graph), "hzb_launch": "separate launches" if (args.hzb_launch == "separate" or args.async_compute) else ("whole chain rides with the Lighting launch" if args.hzb_launch == "ride" else "tail rides with the Lighting launch"), "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
         },
         "roofline": {
             "kernel": "lighting_stream_kernel<FUSED>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float(light_ms.min()) * 1e3,
+            "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float((light_ms - record_ms).min()) * 1e3,
+            "event_bracket_us": bracket_avg_s * 1e6, "event_record_us": record_avg_s * 1e6,
+            "frac_uncorrected": light_bytes / bracket_avg_s / 1e9 / HBM_PEAK_GBS,
             "shade_only_mpixels_per_s": g.depth.size * N / light_avg_s / 1e6,
             "launches_sampled": int(light_ms.size), "alone_on_stream_us": float(alone_ms.mean()) * 1e3,
             "alone_on_stream_frac": light_bytes / (float(alone_ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -135,8 +135,14 @@ int ur_reserve(ur_ctx* ctx, uint32_t max_instances);
  * held-back tail on its own first. ur_destroy() DISCARDS it (the HZB buffer may already be gone). While a tail is held
  * back, ur_build_hzb has returned UR_OK with the levels of the tail still unwritten: a caller that reads the HZB by other
  * means (its own kernels, a copy, another context or stream) calls ur_flush() first, and keeps the HZB buffer alive until
- * then. Off by default. */
-int ur_defer_hzb_tail(ur_ctx* ctx, int enable);
+ * then. Off by default.
+ * ur_defer_hzb_tail(ctx, 2) holds back the WHOLE chain when it is one five-level launch from the depth buffer plus the tail
+ * (every frame size from a few hundred pixels up to 8K is): ur_build_hzb then launches nothing; the next streaming Lighting
+ * launch walks the wide launch's 128x32 pieces with one wave of each of its workgroups (memory-bound work beside the
+ * compute-bound shading) and its extra tail workgroup waits, inside the launch, for their arrival counter before it reduces
+ * the rest. Same bits, same rules as above (flush / cull / rebuild / a per-tile Lighting launch send the ordinary launches
+ * out first); the depth buffer must stay unchanged until then as well. */
+int ur_defer_hzb_tail(ur_ctx* ctx, int mode /* 0 off, 1 tail, 2 whole chain */);
 int ur_flush(ur_ctx* ctx);
 const char* ur_last_error(void);
 const char* ur_version(void);

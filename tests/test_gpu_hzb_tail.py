@@ -161,7 +161,7 @@ def test_frame_flag_gives_the_same_frame(hotpath):
     bounds = to_device(synth.instances_random(n, 2, center=fc.camera_position, box=60.0))
     consts = hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, False)
     outs = []
-    for extra in (0, lib.UR_FRAME_HZB_TAIL_WITH_LIGHTING):
+    for extra in (0, lib.UR_FRAME_HZB_TAIL_WITH_LIGHTING, lib.UR_FRAME_HZB_WITH_LIGHTING):
         frame = Frame(hotpath)
         hzb = torch.zeros(lay.total, device="cuda")
         d_args = to_device(synth.indirect_args_initial(n))
@@ -174,8 +174,9 @@ def test_frame_flag_gives_the_same_frame(hotpath):
         torch.cuda.synchronize()
         outs.append((hzb.clone(), hdr.clone(), d_args.clone(), d_vis.clone(), d_cnt.clone()))
         frame.close()
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
 
 
 def test_destroy_discards_a_held_back_tail(oracle):
@@ -222,3 +223,58 @@ def test_cull_rejects_a_chain_that_does_not_halve(hotpath):
     with pytest.raises(RuntimeError, match="halve"):
         hotpath.cull_indirect_args(c, bounds, hzb, bad, d_args)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("w,h", [(1024, 512), (512, 256), (1920, 1080), (3840, 2160), (7680, 4320), (1000, 300)])
+def test_whole_chain_rides_with_streaming_lighting(hotpath, w, h):
+    """ur_defer_hzb_tail(ctx, 2): ur_build_hzb launches nothing; the Lighting launch's workgroups walk the wide launch's
+    128x32 pieces (one wave each) and its extra workgroup reduces the tail once they have all arrived. HZB and HDR are
+    bit for bit what the separate launches give, launch after launch (the arrival counter resets itself)."""
+    import torch
+    from unclerenderer_amd.hotpath import to_device
+    if w * h > 4096 * 2160:
+        fc, g, tables, lay, dev = _setup(hotpath, 512, 256)  # small tables; the big frame's G-buffer is synthetic noise
+        import numpy as np
+        from unclerenderer_amd import hostmath, synth
+        from unclerenderer_amd.hotpath import HzbLayout
+        fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=128, env_mip_count=5)
+        g = synth.gbuffer_iid(w, h, 7)
+        lay = HzbLayout(w, h)
+        dev = dict(A=to_device(g.A), B=to_device(g.B), C=to_device(g.C), D=to_device(g.depth))
+    else:
+        fc, g, tables, lay, dev = _setup(hotpath, w, h)
+    assert lay.count > 5
+    ref_hzb, ref_hdr = _reference(hotpath, fc, g, tables, lay, dev, w, h)
+    hotpath.defer_hzb_tail(2)
+    try:
+        for it in range(3):
+            hzb = torch.full((lay.total,), -1.0, device="cuda")
+            hdr = to_device(g.hdr)
+            hotpath.build_hzb(dev["D"], hzb, lay)
+            torch.cuda.synchronize()
+            assert float(hzb[0]) == -1.0 and float(hzb[lay.as_list()[-1][0]]) == -1.0, "nothing of the chain has been launched yet"
+            hotpath.deferred_lighting_sky(fc.scene, fc.sky, dev["A"], dev["B"], dev["C"], dev["D"], tables, hdr, w, h)
+            torch.cuda.synchronize()
+            assert torch.equal(hzb, ref_hzb), f"launch {it}: the Lighting launch built the whole chain"
+            assert torch.equal(hdr, ref_hdr)
+        # held back, then flushed without a Lighting launch: the ordinary launches
+        hzb = torch.full((lay.total,), -1.0, device="cuda")
+        hotpath.build_hzb(dev["D"], hzb, lay)
+        hotpath.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(hzb, ref_hzb)
+        # held back, then a per-tile Lighting launch (lighting-only over 3 rows of a 24-pixel-wide frame): flushed in front
+        hzb = torch.full((lay.total,), -1.0, device="cuda")
+        hotpath.build_hzb(dev["D"], hzb, lay)
+        fc2, g2, tables2, lay2, dev2 = _setup(hotpath, 24, 8, seed=3)
+        hotpath.deferred_lighting_sky(fc2.scene, fc2.sky, dev2["A"], dev2["B"], dev2["C"], dev2["D"], tables2, to_device(g2.hdr), 24, 8)
+        torch.cuda.synchronize()
+        assert torch.equal(hzb, ref_hzb)
+        # switching down to mode 1 flushes a held-back wide launch; the tail alone then rides as before
+        hzb = torch.full((lay.total,), -1.0, device="cuda")
+        hotpath.build_hzb(dev["D"], hzb, lay)
+        hotpath.defer_hzb_tail(1)
+        torch.cuda.synchronize()
+        assert torch.equal(hzb, ref_hzb)
+    finally:
+        hotpath.defer_hzb_tail(0)

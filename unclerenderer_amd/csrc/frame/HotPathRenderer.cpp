@@ -195,7 +195,8 @@ struct ur_frame
     hipStream_t AsyncStream = nullptr;
     ur_ctx* AsyncCtx = nullptr;
     int DeviceIndex = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> LightEvents; // ring of event pairs around the Lighting pass
+    struct FLightEvents { hipEvent_t first, second, after; };
+    std::vector<FLightEvents> LightEvents; // ring: an event pair around the Lighting pass + one more right behind it (what a record costs)
     size_t LightHead = 0, LightCount = 0;
     ur_frame(ur_ctx* Ctx, hipStream_t Stream, uint32 Frames, int Rank, int World) : Cmd(Ctx, Stream, Frames, Rank, World), Renderer(&Device) {}
 };
@@ -209,8 +210,8 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
     f->Renderer.SetLightingTimer([f](hipStream_t s, bool begin) {
         constexpr size_t kRing = 1024;
         if (f->LightEvents.size() < kRing && begin && f->LightCount == f->LightEvents.size()) {
-            hipEvent_t a = nullptr, b = nullptr;
-            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) f->LightEvents.emplace_back(a, b);
+            hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventCreate(&c) == hipSuccess) f->LightEvents.push_back({a, b, c});
         }
         if (f->LightEvents.empty()) return;
         if (begin) {
@@ -218,24 +219,33 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
             (void)hipEventRecord(f->LightEvents[f->LightHead].first, s);
         } else {
             (void)hipEventRecord(f->LightEvents[f->LightHead].second, s);
+            // a third record with nothing in front of it: second -> after is what one event record adds to the bracket
+            (void)hipEventRecord(f->LightEvents[f->LightHead].after, s);
             ++f->LightCount;
         }
     });
     return f;
 }
 
-uint32_t ur_frame_lighting_times(ur_frame* f, float* out_ms, uint32_t cap)
+uint32_t ur_frame_lighting_times_ex(ur_frame* f, float* out_ms, float* out_record_ms, uint32_t cap)
 {
     if (!f) return 0;
     const size_t n = f->LightCount < f->LightEvents.size() ? f->LightCount : f->LightEvents.size();
     uint32_t k = 0;
     for (size_t i = 0; i < n && k < cap; ++i) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, f->LightEvents[i].first, f->LightEvents[i].second) == hipSuccess) out_ms[k++] = ms;
+        float ms = 0.0f, rec = 0.0f;
+        if (hipEventElapsedTime(&ms, f->LightEvents[i].first, f->LightEvents[i].second) != hipSuccess) continue;
+        if (out_record_ms) {
+            if (hipEventElapsedTime(&rec, f->LightEvents[i].second, f->LightEvents[i].after) != hipSuccess) rec = 0.0f;
+            out_record_ms[k] = rec;
+        }
+        out_ms[k++] = ms;
     }
     f->LightCount = 0;
     return k;
 }
+
+uint32_t ur_frame_lighting_times(ur_frame* f, float* out_ms, uint32_t cap) { return ur_frame_lighting_times_ex(f, out_ms, nullptr, cap); }
 
 void ur_frame_destroy(ur_frame* f)
 {
@@ -243,7 +253,7 @@ void ur_frame_destroy(ur_frame* f)
     if (f->AsyncStream) (void)hipStreamSynchronize(f->AsyncStream);
     if (f->AsyncCtx) ur_destroy(f->AsyncCtx);
     if (f->AsyncStream) (void)hipStreamDestroy(f->AsyncStream);
-    for (auto& e : f->LightEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : f->LightEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); (void)hipEventDestroy(e.after); }
     delete f;
 }
 
@@ -299,8 +309,9 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     f->Cmd.SetJoinAsyncAtEnd((flags & UR_FRAME_ASYNC_NO_JOIN) == 0);
     f->Cmd.BeginFrame();
     // Launch scheduling across two passes (include/ur_hotpath.h, ur_defer_hzb_tail): only when both run on the main stream
-    const bool tail_with_lighting = (flags & UR_FRAME_HZB_TAIL_WITH_LIGHTING) != 0 && !O.bAsyncCompute;
-    if (tail_with_lighting) (void)ur_defer_hzb_tail(f->Cmd.GetContext(), 1);
+    const bool chain_with_lighting = (flags & UR_FRAME_HZB_WITH_LIGHTING) != 0 && !O.bAsyncCompute;
+    const bool tail_with_lighting = (chain_with_lighting || (flags & UR_FRAME_HZB_TAIL_WITH_LIGHTING) != 0) && !O.bAsyncCompute;
+    if (tail_with_lighting) (void)ur_defer_hzb_tail(f->Cmd.GetContext(), chain_with_lighting ? 2 : 1);
     const int rc = f->Renderer.RenderFrame(f->Cmd, R, K, O);
     if (tail_with_lighting) {
         const int rc2 = ur_defer_hzb_tail(f->Cmd.GetContext(), 0); // launches the tail on its own if no Lighting launch took it

@@ -13,18 +13,11 @@
 
 #include "ur_internal.h"
 #include "hzb_tail.h"
+#include "hzb_wide.h"
 
 namespace {
 
-struct HzbDispatch {
-    const float* src;
-    float* dst[5];
-    uint32_t SW, SH;
-    uint32_t W[5], H[5];
-    uint32_t mips; // 1..4 as the reference dispatches; 5 = also the first level of the NEXT reference dispatch (see below)
-    uint32_t vec4_ok; // SW % 4 == 0 and src 16-byte aligned
-    uint32_t pair_ok; // W[0] even and dst[0] 8-byte aligned
-};
+using ur::HzbDispatch;
 
 __device__ __forceinline__ float min4(float a, float b, float c, float d) { return fminf(fminf(a, b), fminf(c, d)); }
 
@@ -203,6 +196,18 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
         d.vec4_ok = ((d.SW & 3u) == 0u && (reinterpret_cast<uintptr_t>(d.src) & 15u) == 0u) ? 1u : 0u;
         d.pair_ok = ((d.W[0] & 1u) == 0u && (reinterpret_cast<uintptr_t>(d.dst[0]) & 7u) == 0u) ? 1u : 0u;
         const dim3 grid((d.W[0] + 63u) / 64u, (d.H[0] + 15u) / 16u);
+        // ur_defer_hzb_tail(ctx, 2): a chain that is ONE five-level launch from the depth buffer plus the single-workgroup tail
+        // (1080p, 4K and 8K all are) is held back as a whole: the next streaming Lighting launch takes its 128x32 pieces
+        // along (lighting.hip), ur_flush / a cull / another build launch it the ordinary way
+        if (mip == 0 && n == 5u && ctx->defer_hzb_tail && ctx->defer_hzb_wide && mip_count > 5u &&
+            (uint64_t)mips[5].width * mips[5].height <= kTailTexels && mip_count - 5u <= kTailMaxLevels && ctx->hzb_done != nullptr) {
+            ctx->pending_wide = d;
+            ctx->pending_wide_grid_x = grid.x;
+            ctx->pending_wide_grid_y = grid.y;
+            ctx->hzb_wide_pending = true;
+            mip += n;
+            continue;
+        }
         hipLaunchKernelGGL(hzb_reduce4_kernel, grid, dim3(256), 0, ctx->stream, d);
         UR_HIP_TRY(hipGetLastError());
         mip += n;
@@ -212,6 +217,11 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
 
 int flush_hzb_tail(ur_ctx* ctx)
 {
+    if (ctx->hzb_wide_pending) { // the held-back wide launch goes first (the tail reads what it writes)
+        ctx->hzb_wide_pending = false;
+        hipLaunchKernelGGL(hzb_reduce4_kernel, dim3(ctx->pending_wide_grid_x, ctx->pending_wide_grid_y), dim3(256), 0, ctx->stream, ctx->pending_wide);
+        UR_HIP_TRY(hipGetLastError());
+    }
     if (!ctx->hzb_tail_pending) return UR_OK;
     ctx->hzb_tail_pending = false;
     hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->pending_tail);

@@ -30,6 +30,10 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef UR_ABLATE
+#define UR_ABLATE 0 // diagnostic builds only; see lighting_stream_kernel
+#endif
+
 namespace {
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -485,7 +489,9 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
     if (px >= p.W || r >= p.rows) return;
     const uint32_t py = p.row0 + r;
     const uint32_t i = r * p.W + px; // pixel index inside the band (< 2^29: byte offsets below stay 32-bit)
-    const float ndcx = fmaf((float)px + 0.5f, p.invW2, -1.0f);
+    // ndc.x in the streaming kernel's two-step form (16-pixel tile origin, then the column inside the tile): the same bits
+    // in both kernels, so a fused streaming launch equals Lighting followed by this kernel's Sky launch bit for bit
+    const float ndcx = fmaf((float)(px & ~15u), p.invW2, fmaf((float)(px & 15u), p.invW2, 0.5f * p.invW2 - 1.0f));
     const float ndcy = fmaf((float)py + 0.5f, p.invH2, -1.0f);
 
     if (MODE != ur::UR_MODE_LIGHTING) {
@@ -493,7 +499,11 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
         const float len = __builtin_amdgcn_sqrtf(fmaf(vx, vx, fmaf(vy, vy, 1.0f)));
         const float skyDepth = p.skyNearOverR * len; // Near / (R * unit_dir.z), unit_dir.z = 1/len
         if (skyDepth >= ld<float>(p.depth, i * 4u)) {
-            const F3 sky = sky_pixel(&p, vx, vy);
+            F3 sky = sky_pixel(&p, vx, vy);
+            // the colour is an fp32 value rounded to fp16 in a second step, as in the oracle and in the streaming kernel: kept
+            // apart from the conversion, or hipcc fuses the last FMA with it (v_fma_mixlo_f16: ONE rounding, a different bit in
+            // about one sky pixel in seven thousand)
+            asm volatile("" : "+v"(sky.x), "+v"(sky.y), "+v"(sky.z));
             half4_t o;
             o.x = (_Float16)sky.x; o.y = (_Float16)sky.y; o.z = (_Float16)sky.z; o.w = (_Float16)1.0f;
             st<half4_t>(p.hdr, i * 8u, o);
@@ -505,11 +515,14 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
     const uint32_t gc = ld<uint32_t>(p.C, i * 4u);
     const half4_t d = ld<half4_t>(p.hdr, i * 8u);
     const F3 col = shade_pixel<SHADOWS>(p, srgb, p.envMipOffset, ndcx * p.invP11, -ndcy * p.invP22, ga, gb, gc);
+    // blend in fp32, then ONE conversion to fp16 (not a fused mixed-precision add: see the sky branch above)
+    float bx = (float)d.x + col.x, by = (float)d.y + col.y, bz = (float)d.z + col.z, bw = (float)d.w + 1.0f;
+    asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz), "+v"(bw));
     half4_t o;
-    o.x = (_Float16)((float)d.x + col.x);
-    o.y = (_Float16)((float)d.y + col.y);
-    o.z = (_Float16)((float)d.z + col.z);
-    o.w = (_Float16)((float)d.w + 1.0f);
+    o.x = (_Float16)bx;
+    o.y = (_Float16)by;
+    o.z = (_Float16)bz;
+    o.w = (_Float16)bw;
     st<half4_t>(p.hdr, i * 8u, o);
 }
 
@@ -534,7 +547,8 @@ constexpr uint32_t kLdsSrgb = 0;                                    // 256 float
 constexpr uint32_t kLdsWork = 1024 + 17 * 32 + 6 * 16 * 16;         // the workgroup's tile counter (one dword, 16 reserved)
 constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
 constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // up to 6 * 4 * 4 float4 (irradiance mip, N <= 2)
-constexpr uint32_t kLdsLut = kLdsIrr + 6 * 16 * 16 + 16;            // (kLutW + 2) x (kLutH + 2) float2
+constexpr uint32_t kLdsHzb = kLdsIrr + 6 * 16 * 16 + 16;            // 80 floats: mip-2 / mip-3 scratch of the wave that walks HZB pieces
+constexpr uint32_t kLdsLut = kLdsHzb + 80 * 4;                      // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
 static_assert(kLdsTiles % 16 == 0, "tile buffers are 16-byte aligned");
@@ -606,7 +620,7 @@ __device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pix
 template <int MODE, class P>
 __device__ __forceinline__ void tile_prefetch(P p, uint32_t W, uint32_t rows, const TileSrc& full, uint32_t lane, uint32_t tx, uint32_t ty, uint32_t lds_dst)
 {
-    const uint32_t origin = (ty * 4u) * W + tx * 16u, rowsLeft = rows - ty * 4u; // uniform
+    const uint32_t origin = (UR_ABLATE & 64) ? 0u : (ty * 4u) * W + tx * 16u, rowsLeft = rows - ty * 4u; // uniform
     if (rowsLeft >= 4u) tile_dma(full, origin, lds_dst);
     else {
         // cold path (the one partial tile row of a band): the lane index goes through an opaque move so that nothing derived
@@ -671,14 +685,17 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 
 // Diagnostic builds only (tools/build_variants.py): UR_ABLATE removes one part of the loop so that its cost can be read off
 // a timing; the output of such a build is wrong by construction. 1: no cube filter (loads kept), 2: no cube lookups at all,
-// 4: no irradiance lookup, 8: no BRDF LUT lookup, 16: no shading at all (DMA in, store out), 32: sRGB decode without the table.
-#ifndef UR_ABLATE
-#define UR_ABLATE 0
-#endif
+// 4: no irradiance lookup, 8: no BRDF LUT lookup, 16: no shading at all (DMA in, store out), 32: sRGB decode without the table,
+// 64: every tile is read from and written to the frame's first tile (no HBM traffic: what the arithmetic alone takes).
 // HDR store flavour: 0 plain, 1 nontemporal (nt), 2 write-through (sc1): what the launch leaves dirty in L2 is written back
 // at its end, on the critical path of the next launch.
 #ifndef UR_HDR_STORE
 #define UR_HDR_STORE 0
+#endif
+// 1: the shadow taps are the FIRST gathers of an iteration (they need only the pixel's position and depth and the wave's
+// lit flag), so that their filter - the first consumer of any gather - finds them landed
+#ifndef UR_SHADOW_FIRST
+#define UR_SHADOW_FIRST 0
 #endif
 __device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint32_t lo, uint32_t hi)
 {
@@ -694,8 +711,17 @@ __device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint
 #endif
 }
 
+// The wide launch of a held-back HZB chain, taken along by the lighting workgroups (ur_defer_hzb_tail(ctx, 2)): workgroup g's
+// last wave walks the 128x32 source pieces g, g + groups, ... before it joins the tile loop (the other waves take up its
+// share of tiles through the LDS work counter), then signals `done`; the riding tail workgroup waits for `groups` arrivals.
+struct HzbRide {
+    ur::HzbDispatch d;
+    uint32_t grid_x, pieces; // pieces == 0: nothing rides
+    uint32_t* done;          // [0] arrivals (reset by the tail workgroup), [1] sticky flag: the tail gave up waiting
+};
+
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
-__global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p, ur::HzbTail hzbTail)
+__global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p, ur::HzbTail hzbTail, HzbRide hzbRide)
 {
     constexpr int kAbl = UR_ABLATE;
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the per-tile kernel");
@@ -714,7 +740,27 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             auto ka = __builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             typedef const __attribute__((address_space(4))) ur::HzbTail* KTail;
-            static_assert(sizeof(LightingParams) % 8 == 0, "the second kernel argument follows the first without padding");
+            typedef const __attribute__((address_space(4))) HzbRide* KRide;
+            static_assert(sizeof(LightingParams) % 8 == 0 && sizeof(ur::HzbTail) % 8 == 0, "the kernel arguments follow one another without padding");
+            const KRide ride = (KRide)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams) + sizeof(ur::HzbTail));
+            if (ride->pieces != 0u) {
+                // The tail's parent level is written by the lighting workgroups of THIS launch: wait for all of them (a relaxed
+                // agent-scope poll by one lane, bounded: a lost arrival must not hang the chip), then acquire, then the barrier
+                // (MI355X_MICROARCH.md, inter-workgroup visibility: valid consumer form).
+                if (threadIdx.x == 0) {
+                    uint32_t* done = ride->done;
+                    const uint32_t want = p.hot.groups;
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                        __builtin_amdgcn_s_sleep(32);
+                        if (++spins > (1u << 22)) { __hip_atomic_store(done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the next launch starts from zero
+                }
+                __syncthreads();
+            }
             ur::hzb_tail_run(*(KTail)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams)), bufA, bufA + ur::kTailTexels);
         }
         return;
@@ -812,6 +858,42 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
+    // ---- a held-back HZB chain's wide launch rides along: this workgroup's pieces, by its last wave, before the tile loop.
+    //      Memory-bound work beside fifteen waves of compute-bound shading; the chain is complete long before the launch is.
+    if constexpr (WPB == 16) {
+        if (wave == WPB - 1u) { // uniform
+            auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            typedef const __attribute__((address_space(4))) HzbRide* KRide;
+            const KRide ride = (KRide)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams) + sizeof(ur::HzbTail));
+            const uint32_t pieces = ride->pieces;
+            if (pieces != 0u) {
+                float* sh2 = reinterpret_cast<float*>(smem + kLdsHzb);
+                const uint32_t gx = ride->grid_x, step = p.hot.groups;
+                for (uint32_t piece = blockIdx.x; piece < pieces; piece += step) { // uniform
+                    const uint32_t by = piece / gx, bx = piece - by * gx;
+                    ur::hzb_wide_piece_by_one_wave(ride->d, bx, by, lane, sh2, sh2 + 64);
+                }
+                // producer side of the hand-off: this wave's stores drained, agent-scope release, then ONE arrival
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // ONE arrival per workgroup: a single-lane device-scope add (agent scope is the default for global atomics on
+                // gfx950). Written as an instruction with EXEC narrowed to lane 0: the same statement as C++ under `if (lane
+                // == 0)` makes hipcc keep the loop's LDS-DMA destination (an SGPR operand of inline asm) in a VGPR.
+                {
+                    uint64_t keep_exec;
+                    const uint32_t zero = 0u, one = 1u;
+                    uint32_t* done = ride->done;
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %1, %2, %3\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(keep_exec)
+                                 : "v"(zero), "v"(one), "s"(done)
+                                 : "memory");
+                }
+            }
+        }
+    }
+
     uint32_t parity = 0;
 // (macro: the statement appears in the shading path and in the all-sky path)
 #define UR_PREFETCH_POINT()                                                                                              \
@@ -868,15 +950,40 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const F3 N = rot(f3(nx * nr, ny * nr, nz * nr), R);
             const float viewZ = -wv;
             const float spec0 = h2f_lo(gb.x), metallic = h2f_hi(gb.x), roughness = h2f_lo(gb.y);
+            const F3 L = f3(p.hot.Lw[0], p.hot.Lw[1], p.hot.Lw[2]);
+            const float NdotL = sat(dot(N, L));
+#if UR_SHADOW_FIRST
+            // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF (direct = 0).
+            const bool wave_direct = __any(NdotL > 0.0f);
+            const bool wave_lit = SHADOWS && wave_direct;
+            f32x3_t sa = {0, 0, 0}, sb = {0, 0, 0}, sc3 = {0, 0, 0};
+            float xa = 0.0f, ya = 0.0f, cmp = 0.0f, sfx = 0.0f, sfy = 0.0f;
+            bool fast = true;
+            if (wave_lit) {
+                // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) = viewZ * (affine in ndc) + constant
+                xa = fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), shT[0]);
+                ya = fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), shT[1]);
+                cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), shT[2]);
+                const float xa0 = floorf(xa), ya0 = floorf(ya);
+                sfx = xa - xa0; sfy = ya - ya0;
+                // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
+                const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, p.hot.shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, p.hot.shadowHm3);
+                fast = ic == xa0 && jc == ya0;
+                const uint32_t o0 = (uint32_t)fmaf(jc, p.hot.shadowWf, ic) * 4u, o1 = o0 + p.hot.shadowRowBytes, o2 = o1 + p.hot.shadowRowBytes;
+                const float* smap = p.hot.shadow;
+                sa = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o0);
+                sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
+                sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const F3 Wd = f3(fmaf(ndcx, p.hot.WA[0], fmaf(ndcy, p.hot.WB[0], WC[0])), fmaf(ndcx, p.hot.WA[1], fmaf(ndcy, p.hot.WB[1], WC[1])),
                              fmaf(ndcx, p.hot.WA[2], fmaf(ndcy, p.hot.WB[2], WC[2]))); // (ra, rb, 1) * ViewInverse3x3
             // V = normalize(-viewPos) = -sign(viewZ) Wd / |Wd|; sign(-viewZ) is the stored sign of A.w
             const float vs = __builtin_copysignf(rsq(dot(Wd, Wd)), wv);
             const F3 V = f3(Wd.x * vs, Wd.y * vs, Wd.z * vs);
-            const F3 L = f3(p.hot.Lw[0], p.hot.Lw[1], p.hot.Lw[2]);
             const float NdotVraw = dot(N, V);
             const float NdotV = sat(NdotVraw);
-            const float NdotL = sat(dot(N, L));
             // ---- global gathers: the two prefiltered mips (bordered cube, addresses in fp32: every integer multiply would hold
             //      the issue port), then the shadow block ------------------------------------------------------------------------
             const float t2 = 2.0f * NdotVraw;
@@ -926,6 +1033,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 pia = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 pib = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + p.hot.irrRowBytes));
             }
+#if !UR_SHADOW_FIRST
             // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF (direct = 0).
             const bool wave_direct = __any(NdotL > 0.0f);
             const bool wave_lit = SHADOWS && wave_direct;
@@ -948,6 +1056,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
                 sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
             }
+#endif
             UR_STAMP(tB);
             // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
             // table byte offsets straight from the packed texel: (c << 2) & 0x3FC, (c >> 6) & 0x3FC, (c >> 14) & 0x3FC
@@ -1105,7 +1214,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z; o.w = (_Float16)outw;
             uint2 ob;
             __builtin_memcpy(&ob, &o, 8);
-            store_hdr(p.hot.hdr, ((ty * 4u) * p.hot.W + tx * 16u) * 8u + laneHdr, ob.x, ob.y);
+            store_hdr(p.hot.hdr, ((kAbl & 64) ? 0u : ((ty * 4u) * p.hot.W + tx * 16u) * 8u) + laneHdr, ob.x, ob.y);
         }
 #ifdef UR_STAMPS
         UR_STAMP(tF);
@@ -1194,9 +1303,20 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     const int cus = std::max(ctx->cu_count, 1);
     const int leave_cus = std::min(leave_env, cus - 1);
     const bool carry_tail = ctx->hzb_tail_pending && WPB == 16 && cus >= 16 && cus - leave_cus >= 2;
+    HzbRide ride{};
     if (carry_tail) {
         tail = ctx->pending_tail;
         ctx->hzb_tail_pending = false;
+        if (ctx->hzb_wide_pending) { // the whole chain rides: the lighting workgroups take the wide launch's pieces along
+            ride.d = ctx->pending_wide;
+            ride.grid_x = ctx->pending_wide_grid_x;
+            ride.pieces = ctx->pending_wide_grid_x * ctx->pending_wide_grid_y;
+            ride.done = ctx->hzb_done;
+            ctx->hzb_wide_pending = false;
+        }
+    } else if (ctx->hzb_wide_pending) { // cannot ride (12-wave build, tiny device): the ordinary launches, in front
+        const int frc = ur::flush_hzb_tail(ctx);
+        if (frc != UR_OK) return frc;
     }
     const uint32_t groups = std::min<uint32_t>((uint32_t)std::max(1, cus - (carry_tail ? 1 : 0) - leave_cus), (h.numTiles + WPB - 1) / WPB);
     h.groups = groups;
@@ -1204,7 +1324,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
     static const int chunk_shift = env_int("UR_LIGHTING_CHUNK_SHIFT", 2); // 4K: chunks of 16 / 4 / 1 tiles -> 75.4 / 74.6 / 79.1 us
     h.chunkShift = (uint32_t)std::min(std::max(chunk_shift, 0), 4);
-    hipLaunchKernelGGL(kern, dim3(groups + (carry_tail ? 1u : 0u)), dim3(64 * WPB), lds, ctx->stream, p, tail);
+    hipLaunchKernelGGL(kern, dim3(groups + (carry_tail ? 1u : 0u)), dim3(64 * WPB), lds, ctx->stream, p, tail, ride);
     return UR_OK;
 }
 

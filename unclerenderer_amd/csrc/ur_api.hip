@@ -132,6 +132,11 @@ ur_ctx* ur_create(int device, void* stream)
         ur_destroy(ctx);
         return nullptr;
     }
+    if (hipMalloc(&ctx->hzb_done, 64) != hipSuccess || hipMemset(ctx->hzb_done, 0, 64) != hipSuccess) {
+        set_error("ur_create: HZB arrival counter allocation failed");
+        ur_destroy(ctx);
+        return nullptr;
+    }
     if (ur_reserve(ctx, 1u << 20) != UR_OK) {
         ur_destroy(ctx);
         return nullptr;
@@ -145,6 +150,8 @@ void ur_destroy(ur_ctx* ctx)
     // A held-back HZB tail is DISCARDED, not launched: the caller may already have freed the HZB buffer it points into (the
     // chain is complete only after ur_flush or a streaming Lighting launch — see ur_build_hzb in the header).
     ctx->hzb_tail_pending = false;
+    ctx->hzb_wide_pending = false;
+    if (ctx->hzb_done) (void)hipFree(ctx->hzb_done);
     if (ctx->srgb_table) (void)hipFree(ctx->srgb_table);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
@@ -154,8 +161,11 @@ void ur_destroy(ur_ctx* ctx)
 int ur_defer_hzb_tail(ur_ctx* ctx, int enable)
 {
     if (!ctx) { set_error("ur_defer_hzb_tail: null context"); return UR_EINVAL; }
+    if (enable < 0 || enable > 2) { set_error("ur_defer_hzb_tail: mode %d (0 off, 1 tail, 2 whole chain)", enable); return UR_EINVAL; }
+    const bool narrower = (enable == 0) || (enable == 1 && ctx->defer_hzb_wide);
     ctx->defer_hzb_tail = enable != 0;
-    return enable ? UR_OK : ur::flush_hzb_tail(ctx);
+    ctx->defer_hzb_wide = enable == 2;
+    return narrower ? ur::flush_hzb_tail(ctx) : UR_OK;
 }
 
 int ur_flush(ur_ctx* ctx)

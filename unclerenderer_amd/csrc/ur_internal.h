@@ -19,6 +19,7 @@ struct HzbTail {
     uint32_t magic[kTailMaxLevels]; // i / W[l] == __umulhi(i, magic[l]) for i < 16384 (magic = 2^32 / W + 1)
 };
 } // namespace ur
+#include "hzb_wide.h"
 
 struct ur_ctx {
     int device = 0;
@@ -35,6 +36,13 @@ struct ur_ctx {
     bool defer_hzb_tail = false;
     bool hzb_tail_pending = false;
     ur::HzbTail pending_tail{};
+    // ur_defer_hzb_tail(ctx, 2): the wide launch in front of the tail is held back too; the Lighting launch's workgroups take its
+    // 128x32 pieces along (one wave of each) and signal `hzb_done`, which the riding tail workgroup waits for.
+    bool defer_hzb_wide = false;
+    bool hzb_wide_pending = false;
+    ur::HzbDispatch pending_wide{};
+    uint32_t pending_wide_grid_x = 0, pending_wide_grid_y = 0;
+    uint32_t* hzb_done = nullptr; // device: [0] arrivals of the current launch (reset by the tail workgroup), [1] sticky time-out flag
 };
 
 namespace ur {

@@ -76,8 +76,9 @@ class HotPath:
     def reserve(self, max_instances: int):
         _lib.check(self._L.ur_reserve(self._ctx, max_instances), "ur_reserve")
 
-    def defer_hzb_tail(self, enable: bool):
-        """Hold back the single-workgroup tail of build_hzb so that it rides along with the next streaming lighting launch."""
+    def defer_hzb_tail(self, enable: "bool | int"):
+        """1 / True: hold back the single-workgroup tail of build_hzb so that it rides along with the next streaming lighting
+        launch; 2: hold back the whole chain (the lighting workgroups take the wide launch's pieces along too); 0: off."""
         _lib.check(self._L.ur_defer_hzb_tail(self._ctx, int(enable)), "ur_defer_hzb_tail")
 
     def flush(self):
@@ -191,6 +192,12 @@ class Frame:
         buf = np.zeros(1024, np.float32)
         n = self._L.ur_frame_lighting_times(self._f, _lib.fptr(buf), 1024)
         return buf[:n].copy()
+
+    def lighting_times_and_record_cost_ms(self):
+        """(bracket durations, cost of one event record behind each bracket) of the passes timed with UR_FRAME_TIME_LIGHTING."""
+        buf, rec = np.zeros(1024, np.float32), np.zeros(1024, np.float32)
+        n = self._L.ur_frame_lighting_times_ex(self._f, _lib.fptr(buf), _lib.fptr(rec), 1024)
+        return buf[:n].copy(), rec[:n].copy()
 
     def join_async(self):
         self._L.ur_frame_join_async(self._f)

@@ -105,6 +105,7 @@ UR_FRAME_INDIRECT_DRAW, UR_FRAME_HZB, UR_FRAME_DEPTH_PREPASS, UR_FRAME_SHADOWS, 
 UR_FRAME_FUSE_LIGHTING_SKY, UR_FRAME_GPU_TIMING, UR_FRAME_GRAPH_DUMP, UR_FRAME_BARRIER_LOGS = 0x20, 0x40, 0x80, 0x100
 UR_FRAME_ASYNC_COMPUTE, UR_FRAME_ASYNC_NO_JOIN, UR_FRAME_TONEMAP, UR_FRAME_TIME_LIGHTING = 0x200, 0x400, 0x800, 0x1000
 UR_FRAME_HZB_TAIL_WITH_LIGHTING = 0x2000
+UR_FRAME_HZB_WITH_LIGHTING = 0x4000
 UR_FRAME_DEFAULT = UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY
 
 assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
@@ -152,6 +153,7 @@ SIGNATURES = {
     "ur_frame_render": (C.c_int, [_VP, C.POINTER(FrameResources), C.POINTER(_U32), C.POINTER(SceneConstants), C.POINTER(SkyConstants), _U32]),
     "ur_frame_join_async": (None, [_VP]),
     "ur_frame_lighting_times": (_U32, [_VP, _FP, _U32]),
+    "ur_frame_lighting_times_ex": (_U32, [_VP, _FP, _FP, _U32]),
     "ur_frame_hzb_ready": (C.c_int, [_VP]),
     "ur_frame_reset_hzb": (None, [_VP]),
     "ur_frame_report": (_U32, [_VP, C.c_char_p, _U32]),
