@@ -19,7 +19,16 @@ __device__ __forceinline__ float hzb_min4(float a, float b, float c, float d) { 
 // 2x2 of its parent's lanes, where an out-of-range parent lane holds 1.0 if the parent was a first level and 0.0
 // otherwise (BuildHZB.hlsl:47,81,104).
 
-template <uint32_t TRIPS, class P>
+// AGENT_LOADS: the parent level was written by other workgroups of the SAME launch (write-through, `sc1`): read it with
+// agent-scope loads, which are served by L2 and never by this CU's L1.
+template <bool AGENT_LOADS>
+__device__ __forceinline__ float tail_load(const float* q)
+{
+    if (AGENT_LOADS) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *q;
+}
+
+template <uint32_t TRIPS, bool AGENT_LOADS, class P>
 __device__ __forceinline__ void tail_first_level(const P& p, float* bufA)
 {
     const uint32_t tid = threadIdx.x, W = p.W[0], n = W * p.H[0];
@@ -35,8 +44,8 @@ __device__ __forceinline__ void tail_first_level(const P& p, float* bufA)
         in2[k] = first || 2u * y + 1u < p.SH;
         const uint32_t x0 = min(2u * x, p.SW - 1u), x1 = min(2u * x + 1u, p.SW - 1u);
         const uint32_t y0 = min(2u * y, p.SH - 1u) * p.SW, y1 = min(2u * y + 1u, p.SH - 1u) * p.SW;
-        t[k][0] = p.src[y0 + x0]; t[k][1] = p.src[y0 + x1];
-        t[k][2] = p.src[y1 + x0]; t[k][3] = p.src[y1 + x1];
+        t[k][0] = tail_load<AGENT_LOADS>(p.src + y0 + x0); t[k][1] = tail_load<AGENT_LOADS>(p.src + y0 + x1);
+        t[k][2] = tail_load<AGENT_LOADS>(p.src + y1 + x0); t[k][3] = tail_load<AGENT_LOADS>(p.src + y1 + x1);
     }
 #pragma unroll
     for (uint32_t k = 0; k < TRIPS; ++k) {
@@ -50,14 +59,14 @@ __device__ __forceinline__ void tail_first_level(const P& p, float* bufA)
 }
 
 // 1024 threads; bufA holds kTailTexels floats, bufB half as many (LDS)
-template <class P> // P = HzbTail in any address space
+template <bool AGENT_LOADS = false, class P> // P = HzbTail in any address space
 __device__ __forceinline__ void hzb_tail_run(const P& p, float* bufA, float* bufB)
 {
     const uint32_t tid = threadIdx.x;
     // first level of the tail: parent in global memory. Every load of the thread is issued before the first reduction:
     // one memory latency (8 or 16 texels x 4 taps).
-    if (p.W[0] * p.H[0] <= kTailTexels / 2u) tail_first_level<kTailTexels / 2048u>(p, bufA);
-    else tail_first_level<kTailTexels / 1024u>(p, bufA);
+    if (p.W[0] * p.H[0] <= kTailTexels / 2u) tail_first_level<kTailTexels / 2048u, AGENT_LOADS>(p, bufA);
+    else tail_first_level<kTailTexels / 1024u, AGENT_LOADS>(p, bufA);
     __syncthreads();
     for (uint32_t l = 1; l < p.levels; ++l) { // uniform
         const float* par = (l & 1u) ? bufA : bufB;

@@ -30,7 +30,11 @@ __device__ __forceinline__ float hzbw_min4(float a, float b, float c, float d) {
 // One 128x32 source piece (bx, by) of a five-level dispatch (p.mips == 5), walked by ONE wave: pass q covers the rows the
 // workgroup form gives to its wave q. sh2: 64 floats, sh3: 16 floats of LDS private to the wave. P: HzbDispatch in any
 // address space (the lighting kernel reads it from its kernarg segment).
-template <class P>
+// HAND_OFF: mip 4 is read by another workgroup of the SAME launch (the riding tail): its texels are stored write-through
+// (agent scope, `sc1`) so that a drained vmcnt plus one arrival is the whole producer side - no L2 write-back fence, which
+// would have to sweep everything the lighting waves have dirtied (MI355X_MICROARCH.md, inter-workgroup visibility, row 1 of
+// the measured sc1 hand-offs: 4-byte sc1 stores, one arrival per storing workgroup, sc1 loads behind the consumer's barrier).
+template <bool HAND_OFF, class P>
 __device__ __forceinline__ void hzb_wide_piece_by_one_wave(const P& p, uint32_t bx, uint32_t by, uint32_t lane, float* sh2, float* sh3)
 {
     const uint32_t tx = lane & 31u, tyw = lane >> 5; // the lane's place in a 32x2 slice of 4x4 source blocks
@@ -127,7 +131,10 @@ __device__ __forceinline__ void hzb_wide_piece_by_one_wave(const P& p, uint32_t 
         if (x4 < p.W[4] && y4 < p.H[4]) {
             const uint32_t c0 = min(2u * x4, p.W[3] - 1u) & 7u, c1 = min(2u * x4 + 1u, p.W[3] - 1u) & 7u;
             const uint32_t r0 = min(2u * y4, p.H[3] - 1u) & 1u, r1 = min(2u * y4 + 1u, p.H[3] - 1u) & 1u;
-            p.dst[4][(size_t)y4 * p.W[4] + x4] = hzbw_min4(sh3[r0 * 8u + c0], sh3[r0 * 8u + c1], sh3[r1 * 8u + c0], sh3[r1 * 8u + c1]);
+            const float v4 = hzbw_min4(sh3[r0 * 8u + c0], sh3[r0 * 8u + c1], sh3[r1 * 8u + c0], sh3[r1 * 8u + c1]);
+            float* d4 = p.dst[4] + (size_t)y4 * p.W[4] + x4;
+            if (HAND_OFF) __hip_atomic_store(reinterpret_cast<uint32_t*>(d4), __float_as_uint(v4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *d4 = v4;
         }
     }
 }

@@ -546,8 +546,8 @@ constexpr uint32_t kLutW = 128, kLutH = 32, kLutE = kLutW + 2;    // streaming k
 constexpr uint32_t kLdsSrgb = 0;                                    // 256 floats
 constexpr uint32_t kLdsWork = 1024 + 17 * 32 + 6 * 16 * 16;         // the workgroup's tile counter (one dword, 16 reserved)
 constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
-constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // up to 6 * 4 * 4 float4 (irradiance mip, N <= 2)
-constexpr uint32_t kLdsHzb = kLdsIrr + 6 * 16 * 16 + 16;            // 80 floats: mip-2 / mip-3 scratch of the wave that walks HZB pieces
+constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradiance mip (N <= 2): 6 * 4 * 4 texels, or 6 * 3 * 3 cells of 64 B (UR_TRIM & 1)
+constexpr uint32_t kLdsHzb = kLdsIrr + 6 * 9 * 64 + 16;            // 80 floats: mip-2 / mip-3 scratch of the wave that walks HZB pieces
 constexpr uint32_t kLdsLut = kLdsHzb + 80 * 4;                      // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
@@ -697,6 +697,14 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 #ifndef UR_SHADOW_FIRST
 #define UR_SHADOW_FIRST 0
 #endif
+// bit 0: the LDS irradiance table holds, per bilinear CELL, the polynomial a + b fx + c fy + d fx fy of each channel (one
+// 64-byte entry, three ds_read_b128, ten VALU instructions) instead of texels (four reads, seventeen instructions)
+#ifndef UR_TRIM
+#define UR_TRIM 1
+#endif
+#ifndef UR_RIDE_RELEASE_FENCE
+#define UR_RIDE_RELEASE_FENCE 0 // diagnostic: the producer side of the riding HZB hand-off as plain stores + an agent-scope release fence
+#endif
 __device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint32_t lo, uint32_t hi)
 {
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -761,7 +769,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 }
                 __syncthreads();
             }
-            ur::hzb_tail_run(*(KTail)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams)), bufA, bufA + ur::kTailTexels);
+            if (ride->pieces != 0u) ur::hzb_tail_run<true>(*(KTail)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams)), bufA, bufA + ur::kTailTexels);
+            else ur::hzb_tail_run<false>(*(KTail)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams)), bufA, bufA + ur::kTailTexels);
         }
         return;
     }
@@ -787,9 +796,19 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         lt[k] = p.lut[sy * kLutW + sx];
     }
     const float sv = threadIdx.x < 256u ? p.srgb[threadIdx.x] : 0.0f;
-    half4_t ih = {};
-    const uint32_t irrE = p.irrN0 + 2u, irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
+    half4_t ih = {}, ih10 = {}, ih01 = {}, ih11 = {};
+    const uint32_t irrE = p.irrN0 + 2u;
+#if UR_TRIM & 1
+    const uint32_t irrC = p.irrN0 + 1u, irrCount = IRR_LDS ? 6u * irrC * irrC : 0u; // cells: <= 54
+    if (threadIdx.x < irrCount) {
+        const uint32_t f = threadIdx.x / (irrC * irrC), r = threadIdx.x - f * irrC * irrC, cj = r / irrC, ci = r - cj * irrC;
+        const uint32_t t0 = p.irrOffset0 + (f * irrE + cj) * irrE + ci;
+        ih = p.env[t0]; ih10 = p.env[t0 + 1u]; ih01 = p.env[t0 + irrE]; ih11 = p.env[t0 + irrE + 1u];
+    }
+#else
+    const uint32_t irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
     if (threadIdx.x < irrCount) ih = p.env[p.irrOffset0 + threadIdx.x];
+#endif
     // Tile schedule: chunks of 2^cs consecutive tiles are dealt round-robin to the workgroups (chunks of 4: the per-workgroup
     // work then differs by +-3 %; with 16 the image content makes it +-9 %, with 1 the DRAM locality of a row is lost),
     // dynamically inside a workgroup: a wave takes its next tile from a counter in LDS. The SIMD's oldest-first
@@ -832,7 +851,17 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     {
         if (threadIdx.x == 0) *work = 2u * WPB;
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
+#if UR_TRIM & 1
+        if (threadIdx.x < irrCount) {
+            // value(fx, fy) = t00 + (t10 - t00) fx + (t01 - t00) fy + (t11 - t10 - t01 + t00) fx fy, per channel
+            const float a[3] = {(float)ih.x, (float)ih.y, (float)ih.z}, b[3] = {(float)ih10.x, (float)ih10.y, (float)ih10.z};
+            const float c[3] = {(float)ih01.x, (float)ih01.y, (float)ih01.z}, d[3] = {(float)ih11.x, (float)ih11.y, (float)ih11.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) irrT[threadIdx.x * 4u + k] = float4a{a[k], b[k] - a[k], c[k] - a[k], (d[k] - b[k]) - (c[k] - a[k])};
+        }
+#else
         if (threadIdx.x < irrCount) irrT[threadIdx.x] = float4a{(float)ih.x, (float)ih.y, (float)ih.z, 0.0f};
+#endif
         if (threadIdx.x < 17u) {
             const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
             const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
@@ -872,11 +901,15 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const uint32_t gx = ride->grid_x, step = p.hot.groups;
                 for (uint32_t piece = blockIdx.x; piece < pieces; piece += step) { // uniform
                     const uint32_t by = piece / gx, bx = piece - by * gx;
-                    ur::hzb_wide_piece_by_one_wave(ride->d, bx, by, lane, sh2, sh2 + 64);
+                    ur::hzb_wide_piece_by_one_wave<true>(ride->d, bx, by, lane, sh2, sh2 + 64);
                 }
-                // producer side of the hand-off: this wave's stores drained, agent-scope release, then ONE arrival
+                // producer side of the hand-off: mip 4 was stored write-through (sc1); this wave's stores drained, then ONE
+                // arrival. (A release fence instead would write back everything the lighting waves have dirtied in this
+                // XCD's L2: measured, it made the launch 17 us longer.)
+#if UR_RIDE_RELEASE_FENCE
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // ONE arrival per workgroup: a single-lane device-scope add (agent scope is the default for global atomics on
                 // gfx950). Written as an instruction with EXEC narrowed to lane 0: the same statement as C++ under `if (lane
@@ -1083,6 +1116,15 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
                 const float fx = x - i0, fy = y - j0;
+#if UR_TRIM & 1
+                // cell (i0, j0) of the face: irrEf / irrEEf hold N + 1 and (N + 1)^2 in this build
+                const float4a* t = irrT + 4u * (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
+                const float4a cx = t[0], cy = t[1], cz = t[2];
+                const float fxy = fx * fy;
+                irradiance.x = fmaf(cx.w, fxy, fmaf(cx.z, fy, fmaf(cx.y, fx, cx.x)));
+                irradiance.y = fmaf(cy.w, fxy, fmaf(cy.z, fy, fmaf(cy.y, fx, cy.x)));
+                irradiance.z = fmaf(cz.w, fxy, fmaf(cz.z, fy, fmaf(cz.y, fx, cz.x)));
+#else
                 const uint32_t E = p.hot.irrN0 + 2u;
                 const float4a* t = irrT + (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
                 const float4a t00 = t[0], t10 = t[1], t01 = t[E], t11 = t[E + 1];
@@ -1091,6 +1133,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 irradiance.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
                 irradiance.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
                 irradiance.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00 * t00.z)));
+#endif
             }
             // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) ----------------------------------------
             const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
@@ -1509,6 +1552,9 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
             h.envMaxLevel = (float)(p.envMips - 1u);
             const uint32_t iE = p.irrN0 + 2u;
             h.irrN0 = p.irrN0; h.irrNf = (float)p.irrN0; h.irrEf = (float)iE; h.irrEEf = (float)(iE * iE);
+#if UR_TRIM & 1
+            if (p.irrN0 <= 2u) { h.irrEf = (float)(p.irrN0 + 1u); h.irrEEf = (float)((p.irrN0 + 1u) * (p.irrN0 + 1u)); } // LDS table of cells
+#endif
             h.irrOfff = (float)p.irrOffset0; h.irrRowBytes = iE * 8u;
             h.env = p.env; h.hdr = p.hdr;
             for (int k = 0; k < 9; ++k) h.R[k] = p.R[k];
