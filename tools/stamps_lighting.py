@@ -73,6 +73,7 @@ def main():
     print(f"{len(a)} waves, {it:.0f} shaded iterations, {tot / it:.0f} cycles per iteration (stamped build)")
     for i, n in enumerate(names):
         print(f"  {n:45s} {a[:, i].sum() / it:8.0f} cycles  {100 * a[:, i].sum() / tot:5.1f} %")
+    print(f"  of the last segment: DMA issue (prefetch point)   {a[:, 13].sum() / it:8.0f} cycles; the HDR store (convert + issue) {a[:, 14].sum() / it:8.0f} cycles")
     per_wave = a[:, :5].sum(axis=1)
     q = np.percentile(per_wave, [0, 5, 25, 50, 75, 95, 100])
     print("per-wave loop cycles (sum over its iterations): min/5/25/50/75/95/max =", " ".join(f"{x:.0f}" for x in q))

@@ -33,6 +33,9 @@
 #ifndef UR_ABLATE
 #define UR_ABLATE 0 // diagnostic builds only; see lighting_stream_kernel
 #endif
+#ifndef UR_DMA_NT
+#define UR_DMA_NT 1 // the tile DMAs carry the nontemporal hint: the G-buffer is read exactly once (4K: 73.9 -> 72.5 us)
+#endif
 
 namespace {
 
@@ -609,8 +612,13 @@ __device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pix
     const char* g1 = s.p1 + (uint64_t)origin * 8u;
     const char* g2 = s.p2 + (uint64_t)origin * s.mul2 - 1024;
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+#if UR_DMA_NT
+#define UR_DMA_POLICY " nt"
+#else
+#define UR_DMA_POLICY ""
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" UR_DMA_POLICY "\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024" UR_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(g1), "v"(g2), "s"(lds_dst)
                  : "memory");
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         }                                                                                                                \
     } while (0)
 #ifdef UR_STAMPS
-    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0, iters = 0;
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tE2 = 0, tF = 0, tG = 0, sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0, sum5 = 0, sum6 = 0, iters = 0;
     UR_STAMP(tL);
 #endif
     while (have0) {
@@ -1195,6 +1203,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             UR_STAMP(tE);
             UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
+            UR_STAMP(tE2);
             // ---- filter, combine ---------------------------------------------------------------------------------------------------
             const float sh_l = shadow * NdotL;
             F3 prefiltered;
@@ -1252,6 +1261,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
         }
+        UR_STAMP(tG);
         if (ty * 4u + row < p.hot.rows) { // false only in the rows a partial bottom tile hangs over the band
             half4_t o;
             o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z; o.w = (_Float16)outw;
@@ -1261,7 +1271,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         }
 #ifdef UR_STAMPS
         UR_STAMP(tF);
-        if (tE != 0) { sum0 += tB - tA; sum1 += tC - tB; sum2 += tD - tC; sum3 += tE - tD; sum4 += tF - tE; iters += 1; }
+        if (tE != 0) { sum0 += tB - tA; sum1 += tC - tB; sum2 += tD - tC; sum3 += tE - tD; sum4 += tF - tE; sum5 += tE2 - tE; sum6 += tF - tG; iters += 1; }
         tE = 0;
 #endif
         if (!more1) break;
@@ -1276,7 +1286,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         UR_STAMP(tX);
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
         o[0] = sum0; o[1] = sum1; o[2] = sum2; o[3] = sum3; o[4] = sum4; o[5] = iters | ((r1 - r0) << 16);
-        o[8] = tP1 - t0; o[9] = tP2 - t0; o[10] = tP3 - t0; o[11] = tP4 - t0; o[12] = t0;
+        o[8] = tP1 - t0; o[9] = tP2 - t0; o[10] = tP3 - t0; o[11] = tP4 - t0; o[12] = t0; o[13] = sum5; o[14] = sum6;
         o[6] = tL - t0; o[7] = tX - t0; // prologue and whole-kernel cycles of this wave; [5] >> 16 = the same span in 100 MHz ticks
     }
 #endif
