@@ -34,7 +34,7 @@
 #define UR_ABLATE 0 // diagnostic builds only; see lighting_stream_kernel
 #endif
 #ifndef UR_DMA_NT
-#define UR_DMA_NT 1 // the tile DMAs carry the nontemporal hint: the G-buffer is read exactly once (4K: 73.9 -> 72.5 us)
+#define UR_DMA_NT 2 // nontemporal hint on the A|B tile DMA: read exactly once (4K: 73.9 -> 72.5 us); the other instruction carries the depth rows, which a riding Build HZB reads again (see tile_dma)
 #endif
 
 namespace {
@@ -612,13 +612,20 @@ __device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pix
     const char* g1 = s.p1 + (uint64_t)origin * 8u;
     const char* g2 = s.p2 + (uint64_t)origin * s.mul2 - 1024;
     uint32_t keep;
-#if UR_DMA_NT
-#define UR_DMA_POLICY " nt"
+    // nontemporal hint (UR_DMA_NT): 1 = both instructions, 2 = the A|B one only (the other carries the depth rows, which a riding
+    // Build HZB reads a second time in the same launch)
+#if UR_DMA_NT == 1
+#define UR_DMA_POLICY1 " nt"
+#define UR_DMA_POLICY2 " nt"
+#elif UR_DMA_NT == 2
+#define UR_DMA_POLICY1 " nt"
+#define UR_DMA_POLICY2 ""
 #else
-#define UR_DMA_POLICY ""
+#define UR_DMA_POLICY1 ""
+#define UR_DMA_POLICY2 ""
 #endif
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" UR_DMA_POLICY "\n\t"
-                 "global_load_lds_dwordx4 %2, off offset:1024" UR_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" UR_DMA_POLICY1 "\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024" UR_DMA_POLICY2 "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(g1), "v"(g2), "s"(lds_dst)
                  : "memory");
