@@ -51,6 +51,7 @@ typedef struct ur_frame_resources {
 #define UR_FRAME_TONEMAP 0x800u /* add the Tonemap pass after Sky (Exposure 0.9, Gamma 2.2, PBR-neutral curve) */
 #define UR_FRAME_TIME_LIGHTING 0x1000u /* bracket the Lighting pass with a HIP event pair on its stream; read with ur_frame_lighting_times() */
 #define UR_FRAME_HZB_TAIL_WITH_LIGHTING 0x2000u /* the single-workgroup tail of Build HZB rides along with the Lighting launch (ur_defer_hzb_tail); ignored with ASYNC_COMPUTE. The Build HZB pass then ends before the chain is complete; the frame is complete when ur_frame_render's launches are */
+#define UR_FRAME_TIME_LIGHTING_RECORD_COST 0x8000u /* TIME_LIGHTING plus one more event recorded right behind the pair: its distance to the pair's closing event is what an event record costs on this queue (ur_frame_lighting_times_ex) */
 #define UR_FRAME_HZB_WITH_LIGHTING 0x4000u /* the WHOLE Build HZB chain rides along with the Lighting launch (ur_defer_hzb_tail(ctx, 2)): its 128x32 pieces are walked by one wave of every lighting workgroup, its tail by an extra workgroup that waits for them; two launches per frame (cull, lighting). Ignored with ASYNC_COMPUTE */
 #define UR_FRAME_DEFAULT (UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY)
 
@@ -67,7 +68,8 @@ void ur_frame_join_async(ur_frame* f);
  * Call after the stream has been synchronised. Returns how many were written. */
 uint32_t ur_frame_lighting_times(ur_frame* f, float* out_ms, uint32_t cap);
 /* The same plus, per sample, the time from the bracket's closing event to one more event recorded right behind it: what a
- * single event record adds to the queue (the bracket contains one such record in front of the kernel). */
+ * single event record adds to the queue (the bracket contains one such record in front of the kernel); -1 for samples taken
+ * without UR_FRAME_TIME_LIGHTING_RECORD_COST. */
 uint32_t ur_frame_lighting_times_ex(ur_frame* f, float* out_ms, float* out_record_ms, uint32_t cap);
 int ur_frame_hzb_ready(const ur_frame* f);
 void ur_frame_reset_hzb(ur_frame* f);

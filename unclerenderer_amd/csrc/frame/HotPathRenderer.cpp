@@ -195,9 +195,10 @@ struct ur_frame
     hipStream_t AsyncStream = nullptr;
     ur_ctx* AsyncCtx = nullptr;
     int DeviceIndex = 0;
-    struct FLightEvents { hipEvent_t first, second, after; };
+    struct FLightEvents { hipEvent_t first, second, after; bool has_after; };
     std::vector<FLightEvents> LightEvents; // ring: an event pair around the Lighting pass + one more right behind it (what a record costs)
     size_t LightHead = 0, LightCount = 0;
+    bool bRecordAfter = false; // this frame's bracket gets the third event (UR_FRAME_TIME_LIGHTING_RECORD_COST)
     ur_frame(ur_ctx* Ctx, hipStream_t Stream, uint32 Frames, int Rank, int World) : Cmd(Ctx, Stream, Frames, Rank, World), Renderer(&Device) {}
 };
 
@@ -211,7 +212,7 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
         constexpr size_t kRing = 1024;
         if (f->LightEvents.size() < kRing && begin && f->LightCount == f->LightEvents.size()) {
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
-            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventCreate(&c) == hipSuccess) f->LightEvents.push_back({a, b, c});
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventCreate(&c) == hipSuccess) f->LightEvents.push_back({a, b, c, false});
         }
         if (f->LightEvents.empty()) return;
         if (begin) {
@@ -220,7 +221,8 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
         } else {
             (void)hipEventRecord(f->LightEvents[f->LightHead].second, s);
             // a third record with nothing in front of it: second -> after is what one event record adds to the bracket
-            (void)hipEventRecord(f->LightEvents[f->LightHead].after, s);
+            f->LightEvents[f->LightHead].has_after = f->bRecordAfter;
+            if (f->bRecordAfter) (void)hipEventRecord(f->LightEvents[f->LightHead].after, s);
             ++f->LightCount;
         }
     });
@@ -236,7 +238,8 @@ uint32_t ur_frame_lighting_times_ex(ur_frame* f, float* out_ms, float* out_recor
         float ms = 0.0f, rec = 0.0f;
         if (hipEventElapsedTime(&ms, f->LightEvents[i].first, f->LightEvents[i].second) != hipSuccess) continue;
         if (out_record_ms) {
-            if (hipEventElapsedTime(&rec, f->LightEvents[i].second, f->LightEvents[i].after) != hipSuccess) rec = 0.0f;
+            rec = -1.0f; // no third event on this sample
+            if (f->LightEvents[i].has_after && hipEventElapsedTime(&rec, f->LightEvents[i].second, f->LightEvents[i].after) != hipSuccess) rec = -1.0f;
             out_record_ms[k] = rec;
         }
         out_ms[k++] = ms;
@@ -302,7 +305,8 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
         if (!f->AsyncCtx) return UR_EHIP;
         f->Cmd.SetAsyncCompute(f->AsyncCtx, f->AsyncStream);
     }
-    O.bTimeLighting = (flags & UR_FRAME_TIME_LIGHTING) != 0;
+    O.bTimeLighting = (flags & (UR_FRAME_TIME_LIGHTING | UR_FRAME_TIME_LIGHTING_RECORD_COST)) != 0;
+    f->bRecordAfter = (flags & UR_FRAME_TIME_LIGHTING_RECORD_COST) != 0;
     O.bGpuTiming = (flags & UR_FRAME_GPU_TIMING) != 0;
     O.bGraphDump = (flags & UR_FRAME_GRAPH_DUMP) != 0;
     O.bBarrierLogs = (flags & UR_FRAME_BARRIER_LOGS) != 0;

@@ -106,6 +106,7 @@ UR_FRAME_FUSE_LIGHTING_SKY, UR_FRAME_GPU_TIMING, UR_FRAME_GRAPH_DUMP, UR_FRAME_B
 UR_FRAME_ASYNC_COMPUTE, UR_FRAME_ASYNC_NO_JOIN, UR_FRAME_TONEMAP, UR_FRAME_TIME_LIGHTING = 0x200, 0x400, 0x800, 0x1000
 UR_FRAME_HZB_TAIL_WITH_LIGHTING = 0x2000
 UR_FRAME_HZB_WITH_LIGHTING = 0x4000
+UR_FRAME_TIME_LIGHTING_RECORD_COST = 0x8000
 UR_FRAME_DEFAULT = UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY
 
 assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
