@@ -59,6 +59,9 @@ def parse():
                     help="add the Tonemap pass behind Lighting+Sky (Tonemap.hlsl) and, with N > 1, all-gather the tonemapped RGBA8 bands "
                          "(4 B/pixel over xGMI) instead of the RGBA16F ones (8 B/pixel)")
     ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
+    ap.add_argument("--timeline", action="store_true",
+                    help="GPU-side timeline of the timed region (ur_debug_timeline: each cull / Lighting launch stamps its first entry and "
+                         "last exit with the constant 100 MHz clock): per-kernel spans and the gaps between consecutive launches, without a profiler")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 1M-instance cull and iid side measurements")
     return ap.parse_args()
@@ -276,12 +279,36 @@ def main():
     for k in range(args.warmup):
         step(k, False)
     fence()
+    tl = None
+    if args.timeline:
+        tl = torch.empty((4 * args.steps + 64, 2), dtype=torch.int64, device=f"cuda:{dev}")
+        tl[:, 0] = -1  # = ~0 as uint64: the entry stamp is an atomic minimum
+        tl[:, 1] = 0
+        torch.cuda.synchronize()
+        hp.debug_timeline(tl)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, True)
     t_enqueued = time.perf_counter() - t0  # host time to submit K frames (if ~= dt the run is submission-bound)
     fence()
     dt = time.perf_counter() - t0
+    timeline = None
+    if tl is not None:
+        hp.debug_timeline(None)
+        pairs = tl.cpu().numpy().view(np.uint64)
+        pairs = pairs[pairs[:, 1] != 0]
+        if pairs.shape[0] >= 8:
+            t_in, t_out = pairs[:, 0].astype(np.float64) * 1e-2, pairs[:, 1].astype(np.float64) * 1e-2  # 100 MHz ticks -> us
+            span = t_out - t_in
+            gap = t_in[1:] - t_out[:-1]
+            big = span > np.median(span) * 3  # the Lighting launches (the cull of a few commands is microseconds)
+            q = lambda a: [round(float(x), 2) for x in np.percentile(a, [50, 90, 100])] if a.size else None
+            timeline = {
+                "launches": int(pairs.shape[0]), "clock": "s_memrealtime, 100 MHz; [median, p90, max] in us",
+                "lighting_span_us": q(span[big]), "other_span_us": q(span[~big]),
+                "gap_before_lighting_us": q(gap[big[1:]]), "gap_before_other_us": q(gap[~big[1:]]),
+                "period_between_lighting_entries_us": q(np.diff(t_in[big])),
+            }
     if N > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -388,6 +415,8 @@ def main():
                                               for k in ("lighting_iid", "lighting_1080p_scene", "lighting_8k_scene")}
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(fc, g, shadow, env, lut, bounds, lay, W, H)
+    if timeline is not None:
+        result["timeline"] = timeline
     if rank == 0:
         result["setup_seconds"] = round(gen_s, 1)
         print(json.dumps(result))

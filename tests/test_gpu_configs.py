@@ -146,15 +146,17 @@ def test_c5_8k_gbuffer_lighting(hotpath, oracle):
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("shadows", [False, True])
-def test_irradiance_mip_gathered_from_memory(hotpath, oracle, fused, shadows):
-    """IRR_LDS = false: EnvMapMipCount - 1 lands on a mip larger than 2x2 (here 8x8), which does not fit the kernel's LDS
-    table: the irradiance taps are global gathers like the prefiltered ones."""
+@pytest.mark.parametrize("env_mip_count,irr_n", [(3, 8), (5, 2), (6, 1)])
+def test_every_irradiance_table_form(hotpath, oracle, fused, shadows, env_mip_count, irr_n):
+    """The irradiance lookup reads mip EnvMapMipCount - 1 of the cube: 1x1 and 2x2 faces live in LDS as per-cell polynomials
+    (24 / 54 cells: the larger table reaches up to the workgroup's tile counter, which must not be touched), anything larger
+    (here 8x8) is gathered from memory like the prefiltered taps (IRR_LDS = false)."""
     import torch
     from unclerenderer_amd import hostmath, synth
     from unclerenderer_amd.hotpath import to_device
     w, h = 320, 180
-    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=256, shadow_strength=1.0 if shadows else 0.0, env_mip_count=3)
-    assert fc.scene.EnvMapMipCount == 3.0  # level 2 of a 32^2 cube = 8x8
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=256, shadow_strength=1.0 if shadows else 0.0, env_mip_count=env_mip_count)
+    assert max(1, 32 >> (env_mip_count - 1)) == irr_n
     env, lut, shadow = synth.env_cube_procedural(32, 6), synth.brdf_lut_procedural(128, 32), synth.shadow_map_noise(256, 41)
     tables = hotpath.make_tables(to_device(shadow) if shadows else None, hotpath.stage_env_cube(env, 32, 6), 32, 6, to_device(lut))
     for g in (synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 41), synth.gbuffer_iid(w, h, 41)):
@@ -178,7 +180,7 @@ from unclerenderer_amd import hostmath, synth
 from unclerenderer_amd.hotpath import HotPath, to_device
 hp = HotPath(0)
 out = {}
-for name, (w, h, mips) in {"lds": (320, 180, 6.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
+for name, (w, h, mips) in {"lds": (320, 180, 6.0), "lds2": (320, 180, 5.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
     fc, g, shadow, env, lut = _lighting_inputs('sponza', w, h, seed=33, mode='scene')
     fc.scene.EnvMapMipCount = mips
     tables = _device_tables(hp, shadow, env, lut)
@@ -205,7 +207,7 @@ def test_twelve_wave_workgroups_give_the_same_bits(hotpath, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UR_LIGHTING_WPB="12"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     child = np.load(dst)
-    for name, (w, h, mips) in {"lds": (320, 180, 6.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
+    for name, (w, h, mips) in {"lds": (320, 180, 6.0), "lds2": (320, 180, 5.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
         fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=33, mode="scene")
         fc.scene.EnvMapMipCount = mips
         tables = _device_tables(hotpath, shadow, env, lut)

@@ -15,6 +15,7 @@
 // run inside one launch.
 
 #include "ur_internal.h"
+#include "ur_device.h"
 
 #include <cstring>
 
@@ -36,6 +37,7 @@ struct CullParams {
     uint32_t index_base;
     uint32_t mip_offset[UR_MAX_HZB_MIPS];
     uint32_t mip_width[UR_MAX_HZB_MIPS];
+    unsigned long long* timeline; // debug: {first entry, last exit} of this launch (ur_debug_timeline), else null
 };
 
 __device__ __forceinline__ float saturate_f(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t first = blockIdx.x * 256u;
     const uint32_t index = first + tid;
+    ur::timeline_entry(C.timeline);
 
     // stage this block's AABBs: 512 float4, lane-consecutive 16-byte loads
     const uint32_t nb = min(512u, (C.ModelCount - first) * 2u);
@@ -157,7 +160,10 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
         }
     }
 
-    if (C.visible_idx == nullptr) return; // uniform
+    if (C.visible_idx == nullptr) { // uniform
+        ur::timeline_exit(C.timeline, tid == 0);
+        return;
+    }
     const uint64_t mask = __ballot(visible);
     if (lane == 0) smask[wave] = mask;
     __syncthreads();
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
         if (lane == 0) C.wave_masks[(size_t)blockIdx.x * 4u + wave] = mask;
         if (tid == 0) C.block_counts[blockIdx.x] = __popcll(smask[0]) + __popcll(smask[1]) + __popcll(smask[2]) + __popcll(smask[3]);
     }
+    ur::timeline_exit(C.timeline, tid == 0);
 }
 
 // Pass 2: one thread per wave mask (64 instances), one workgroup per 256 masks = 64 cull blocks. The workgroup's base is
@@ -229,6 +236,7 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
     P.visible_idx = visible_idx;
     P.visible_count = visible_count;
     P.index_base = index_base;
+    P.timeline = P.ModelCount != 0 ? next_timeline_pair(ctx) : nullptr; // (the compaction launch of a large cull is not stamped)
     if (P.HZBEnabled != 0) {
         for (uint32_t m = 0; m < P.HZBMipCount && m < UR_MAX_HZB_MIPS; ++m) {
             P.mip_offset[m] = mips[m].offset;

@@ -97,6 +97,7 @@ struct LightingParams {
     float sunAttenuation;
     StreamHot hot;       // streaming kernel: everything one loop iteration reads
     unsigned long long* stamps; // diagnostic builds (-DUR_STAMPS): per-wave cycle sums of the loop segments
+    unsigned long long* timeline; // debug: {first entry, last exit} of this launch (ur_debug_timeline), else null
     // buffers
     const half4_t* A;
     const half4_t* B;
@@ -547,10 +548,12 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
 // =====================================================================================================================
 constexpr uint32_t kLutW = 128, kLutH = 32, kLutE = kLutW + 2;    // streaming kernel: LUT dimensions are compile-time
 constexpr uint32_t kLdsSrgb = 0;                                    // 256 floats
-constexpr uint32_t kLdsWork = 1024 + 17 * 32 + 6 * 16 * 16;         // the workgroup's tile counter (one dword, 16 reserved)
+constexpr uint32_t kLdsIrrBytes = 6 * 9 * 64;                       // the larger of the two table forms (6 * 16 texels * 16 B = 1536; 54 cells * 64 B)
+constexpr uint32_t kLdsWork = 1024 + 17 * 32 + kLdsIrrBytes;        // [0] the workgroup's tile counter, [1] waves that left the loop (16 bytes reserved)
 constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
+static_assert(6 * 16 * 16 <= 6 * 9 * 64, "both irradiance table forms fit the region");
 constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradiance mip (N <= 2): 6 * 4 * 4 texels, or 6 * 3 * 3 cells of 64 B (UR_TRIM & 1)
-constexpr uint32_t kLdsHzb = kLdsIrr + 6 * 9 * 64 + 16;            // 80 floats: mip-2 / mip-3 scratch of the wave that walks HZB pieces
+constexpr uint32_t kLdsHzb = kLdsWork + 16;            // 80 floats: mip-2 / mip-3 scratch of the wave that walks HZB pieces
 constexpr uint32_t kLdsLut = kLdsHzb + 80 * 4;                      // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
@@ -755,6 +758,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 #endif
     ur::warm_kernarg<sizeof(LightingParams)>(); // (ur_device.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ur::timeline_entry(p.timeline);
     if (blockIdx.x >= p.hot.groups) { // uniform: the one extra workgroup of a launch that carries a deferred HZB tail (ur_defer_hzb_tail)
         if constexpr (WPB == 16) {
             static_assert(kLdsTiles + 16u * 2u * kTileBytes >= (ur::kTailTexels + ur::kTailTexels / 2u) * sizeof(float), "the tail's two level buffers fit the launch's LDS");
@@ -787,6 +791,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             if (ride->pieces != 0u) ur::hzb_tail_run<true>(*(KTail)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams)), bufA, bufA + ur::kTailTexels);
             else ur::hzb_tail_run<false>(*(KTail)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams)), bufA, bufA + ur::kTailTexels);
         }
+        ur::timeline_exit(p.timeline, threadIdx.x == 0);
         return;
     }
     float* srgb = reinterpret_cast<float*>(smem + kLdsSrgb);
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     }
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
-        if (threadIdx.x == 0) *work = 2u * WPB;
+        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline)
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
 #if UR_TRIM & 1
         if (threadIdx.x < irrCount) {
@@ -1287,6 +1292,11 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         parity ^= 1u;
     }
 #undef UR_PREFETCH_POINT
+    if (p.timeline != nullptr) { // debug timeline: the workgroup's LAST wave to leave the loop stamps the exit (uniform branch)
+        uint32_t left = 0;
+        if (lane == 0) left = __hip_atomic_fetch_add(work + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ur::timeline_exit(p.timeline, lane == 0 && left == WPB - 1u);
+    }
 #ifdef UR_STAMPS
     if (p.stamps && lane == 0) {
         unsigned long long* o = p.stamps + (size_t)(blockIdx.x * WPB + wave) * 16u;
@@ -1342,6 +1352,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     p.stamps = g_stamps;
 #endif
     constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
+    p.timeline = ur::next_timeline_pair(ctx);
     auto kern = lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB>;
     // MaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: one flag per instantiation and device
     static bool attr_set[64] = {};

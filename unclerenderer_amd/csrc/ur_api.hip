@@ -168,6 +168,15 @@ int ur_defer_hzb_tail(ur_ctx* ctx, int enable)
     return narrower ? ur::flush_hzb_tail(ctx) : UR_OK;
 }
 
+int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t capacity_pairs)
+{
+    if (!ctx || (device_pairs != nullptr && capacity_pairs == 0)) { set_error("ur_debug_timeline: bad argument"); return UR_EINVAL; }
+    ctx->timeline = device_pairs;
+    ctx->timeline_cap = device_pairs ? capacity_pairs : 0u;
+    ctx->timeline_pos = 0;
+    return UR_OK;
+}
+
 int ur_flush(ur_ctx* ctx)
 {
     if (!ctx) { set_error("ur_flush: null context"); return UR_EINVAL; }

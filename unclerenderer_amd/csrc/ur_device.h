@@ -54,4 +54,15 @@ __device__ __forceinline__ void warm_kernarg()
 #undef UR_KA_LINE
 }
 
+// Debug timeline (ur_debug_timeline): one lane per workgroup folds the constant 100 MHz clock into the launch's {first entry,
+// last exit} pair. Nothing is executed when the pointer is null (one scalar branch).
+__device__ __forceinline__ void timeline_entry(unsigned long long* pair)
+{
+    if (pair != nullptr && threadIdx.x == 0) atomicMin(pair, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void timeline_exit(unsigned long long* pair, bool lane_of_last_wave)
+{
+    if (pair != nullptr && lane_of_last_wave) atomicMax(pair + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
 } // namespace ur

@@ -81,6 +81,14 @@ class HotPath:
         launch; 2: hold back the whole chain (the lighting workgroups take the wide launch's pieces along too); 0: off."""
         _lib.check(self._L.ur_defer_hzb_tail(self._ctx, int(enable)), "ur_defer_hzb_tail")
 
+    def debug_timeline(self, pairs: "torch.Tensor | None"):
+        """pairs: (n, 2) int64 device tensor initialised to [-1, 0] rows (= {~0, 0} as uint64), or None to switch it off."""
+        if pairs is None:
+            _lib.check(self._L.ur_debug_timeline(self._ctx, None, 0), "ur_debug_timeline")
+        else:
+            assert pairs.dtype == torch.int64 and pairs.dim() == 2 and pairs.shape[1] == 2
+            _lib.check(self._L.ur_debug_timeline(self._ctx, _ptr(pairs), pairs.shape[0]), "ur_debug_timeline")
+
     def flush(self):
         _lib.check(self._L.ur_flush(self._ctx), "ur_flush")
 

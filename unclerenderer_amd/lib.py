@@ -121,6 +121,7 @@ SIGNATURES = {
     "ur_reserve": (C.c_int, [_VP, _U32]),
     "ur_defer_hzb_tail": (C.c_int, [_VP, C.c_int]),
     "ur_flush": (C.c_int, [_VP]),
+    "ur_debug_timeline": (C.c_int, [_VP, _VP, _U32]),
     "ur_last_error": (C.c_char_p, []),
     "ur_version": (C.c_char_p, []),
     "ur_hzb_layout": (_U32, [_U32, _U32, C.POINTER(MipDesc), C.POINTER(_U32)]),
