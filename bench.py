@@ -59,6 +59,14 @@ def parse():
                     help="add the Tonemap pass behind Lighting+Sky (Tonemap.hlsl) and, with N > 1, all-gather the tonemapped RGBA8 bands "
                          "(4 B/pixel over xGMI) instead of the RGBA16F ones (8 B/pixel)")
     ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="host pacing: the host waits (once every 64 frames) until the GPU is within this many frames of it (the reference "
+                         "keeps 3 frames in flight, Core/Application.cpp:567-573). 0 = unpaced (default): the host runs ~8x ahead of the GPU, "
+                         "which is what hides its own pauses")
+    ap.add_argument("--python-gc", action="store_true",
+                    help="leave Python's cyclic garbage collector on during the frames. Off by default: a full collection of this process's "
+                         "heap takes the submitting thread 35-55 ms at an allocation count that falls inside the timed region, and whenever "
+                         "that is longer than the work queued ahead the GPU idles for the difference (the 'slow' bench process, DESIGN.md section 7)")
     ap.add_argument("--timeline", action="store_true",
                     help="GPU-side timeline of the timed region (ur_debug_timeline: each cull / Lighting launch stamps its first entry and "
                          "last exit with the constant 100 MHz clock): per-kernel spans and the gaps between consecutive launches, without a profiler")
@@ -221,7 +229,25 @@ def main():
     # --steps 20) takes three samples. What a record costs is measured OUTSIDE the timed region (calibration frames below).
     light_every = 8 if args.steps >= 64 else max(2, (args.steps + 2) // 3)
 
+    from collections import deque
+    pace_marks = deque()
+    pace_every = 64
+    submitted = [0]
+
+    def pace():
+        """Every 64th frame leaves an event behind; the host never runs more than --frames-in-flight frames ahead of it."""
+        if args.frames_in_flight <= 0:
+            return
+        submitted[0] += 1
+        if submitted[0] % pace_every == 0:
+            e = torch.cuda.Event()
+            e.record()
+            pace_marks.append(e)
+            while len(pace_marks) > max(1, args.frames_in_flight // pace_every):
+                pace_marks.popleft().synchronize()
+
     def step(k: int, timed: bool):
+        pace()
         s = sets[k % ring]
         # one frame in eight carries the event pair: an event record costs ~4 us of queue time on this stack, which would
         # otherwise inflate every timed frame by ~6 %
@@ -265,6 +291,11 @@ def main():
             s["graph"] = g_
     # Untimed frames, in this order: a clock ramp of max(0, min_warmup - W) frames, the host-cost probe's 32, then the W
     # warm-up steps the caller asked for, then the K timed ones. All of them are reported (clock_ramp_frames, warmup).
+    import gc
+    if not args.python_gc:
+        gc.collect()
+        gc.freeze()   # everything allocated during set-up is out of the collector's sight
+        gc.disable()  # and no collection starts while frames are being submitted (re-enabled behind the timed region)
     ramp_frames = max(0, args.min_warmup - args.warmup)
     for k in range(ramp_frames):
         step(k, False)
@@ -286,12 +317,17 @@ def main():
         tl[:, 1] = 0
         torch.cuda.synchronize()
         hp.debug_timeline(tl)
+    host_t = np.zeros(args.steps + 1)
     t0 = time.perf_counter()
+    host_t[0] = t0
     for k in range(args.steps):
         step(args.warmup + k, True)
+        host_t[k + 1] = time.perf_counter()
     t_enqueued = time.perf_counter() - t0  # host time to submit K frames (if ~= dt the run is submission-bound)
     fence()
     dt = time.perf_counter() - t0
+    if not args.python_gc:
+        gc.enable()
     timeline = None
     if tl is not None:
         hp.debug_timeline(None)
@@ -301,7 +337,7 @@ def main():
             t_in, t_out = pairs[:, 0].astype(np.float64) * 1e-2, pairs[:, 1].astype(np.float64) * 1e-2  # 100 MHz ticks -> us
             span = t_out - t_in
             gap = t_in[1:] - t_out[:-1]
-            big = span > np.median(span) * 3  # the Lighting launches (the cull of a few commands is microseconds)
+            big = span > 20.0  # the Lighting launches (the cull of a few commands is microseconds)
             q = lambda a: [round(float(x), 2) for x in np.percentile(a, [50, 90, 100])] if a.size else None
             timeline = {
                 "launches": int(pairs.shape[0]), "clock": "s_memrealtime, 100 MHz; [median, p90, max] in us",
@@ -309,6 +345,16 @@ def main():
                 "gap_before_lighting_us": q(gap[big[1:]]), "gap_before_other_us": q(gap[~big[1:]]),
                 "period_between_lighting_entries_us": q(np.diff(t_in[big])),
             }
+            # the largest GPU-idle gaps, with the frame they precede, beside the host's largest pauses between two submissions:
+            # a GPU gap of milliseconds that sits where the host paused is the host thread not being scheduled / blocked in the
+            # runtime, not anything the kernels do
+            frame_of = np.cumsum(big) - big  # launch index -> frame index (a frame ends with its Lighting launch)
+            top = np.argsort(gap)[-3:][::-1]
+            timeline["largest_gaps"] = [{"us": round(float(gap[i]), 1), "before_frame": int(frame_of[i + 1])} for i in top]
+            hd = np.diff(host_t) * 1e6
+            toph = np.argsort(hd)[-3:][::-1]
+            timeline["largest_host_pauses"] = [{"us": round(float(hd[i]), 1), "submitting_frame": int(i)} for i in toph]
+            timeline["host_submit_us_median"] = round(float(np.median(hd)), 1)
     if N > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -385,7 +431,7 @@ def main():
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
-            "async_compute": args.async_compute, "hip_graph": bool(args.graph), "hzb_launch": "separate launches" if (args.hzb_launch == "separate" or args.async_compute) else ("whole chain rides with the Lighting launch" if args.hzb_launch == "ride" else "tail rides with the Lighting launch"), "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)",
+            "async_compute": args.async_compute, "hip_graph": bool(args.graph), "hzb_launch": "separate launches" if (args.hzb_launch == "separate" or args.async_compute) else ("whole chain rides with the Lighting launch" if args.hzb_launch == "ride" else "tail rides with the Lighting launch"), "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)", "frames_in_flight": args.frames_in_flight,
         },
         "roofline": {
             "kernel": "lighting_stream_kernel<FUSED>" + (" carrying the Build HZB chain (wave pieces + tail workgroup)" if rides else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
