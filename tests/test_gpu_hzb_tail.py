@@ -278,3 +278,44 @@ def test_whole_chain_rides_with_streaming_lighting(hotpath, w, h):
         assert torch.equal(hzb, ref_hzb)
     finally:
         hotpath.defer_hzb_tail(0)
+
+
+def test_debug_timeline_orders_the_launches(hotpath):
+    """ur_debug_timeline: every cull and streaming Lighting launch folds the GPU's constant clock into the next {first entry,
+    last exit} pair of the caller's ring, in launch order; with the chain riding the Lighting pair spans the HZB work too."""
+    import torch
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import to_device
+    w, h, n = 1024, 512, 25
+    fc, g, tables, lay, dev = _setup(hotpath, w, h, seed=5)
+    bounds = to_device(synth.instances_random(n, 2, center=fc.camera_position, box=60.0))
+    d_args = to_device(synth.indirect_args_initial(n))
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, n, False, 0, 0, 0, False)
+    hzb = torch.zeros(lay.total, device="cuda")
+    pairs = torch.zeros((8, 2), dtype=torch.int64, device="cuda")
+    pairs[:, 0] = -1
+    torch.cuda.synchronize()
+    hotpath.debug_timeline(pairs)
+    hotpath.defer_hzb_tail(2)
+    try:
+        for _ in range(3):
+            hotpath.cull_indirect_args(consts, bounds, None, None, d_args)
+            hotpath.build_hzb(dev["D"], hzb, lay)   # held back: no launch, no pair
+            hdr = to_device(g.hdr)
+            hotpath.deferred_lighting_sky(fc.scene, fc.sky, dev["A"], dev["B"], dev["C"], dev["D"], tables, hdr, w, h)
+        torch.cuda.synchronize()
+    finally:
+        hotpath.defer_hzb_tail(0)
+        hotpath.debug_timeline(None)
+    p = pairs.cpu().numpy().view("uint64")
+    used = p[:6]
+    assert (p[6:, 1] == 0).all() and (used[:, 1] != 0).all(), "six launches, six pairs"
+    assert (used[:, 1] > used[:, 0]).all(), "exit after entry"
+    assert (used[1:, 0] >= used[:-1, 1]).all(), "launches of one stream do not overlap: each entry is behind the previous exit"
+    spans_us = (used[:, 1] - used[:, 0]).astype("float64") * 1e-2
+    assert spans_us[0::2].max() < spans_us[1::2].min(), "cull launches are shorter than Lighting launches"
+    # switched off: further launches stamp nothing
+    before = pairs.clone()
+    hotpath.cull_indirect_args(consts, bounds, None, None, d_args)
+    torch.cuda.synchronize()
+    assert torch.equal(pairs, before)
