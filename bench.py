@@ -227,9 +227,10 @@ def main():
     # roofline leg: the Lighting pass of every timed frame is bracketed by a HIP event pair on the stream it is launched on
     timed_flags = flags if args.no_light_events else (flags | urlib.UR_FRAME_TIME_LIGHTING)
 
-    # One timed frame in eight carries the Lighting event pair (two records: ~10 us of queue time); a short run (the driver's
-    # --steps 20) takes three samples. What a record costs is measured OUTSIDE the timed region (calibration frames below).
-    light_every = 8 if args.steps >= 64 else max(2, (args.steps + 2) // 3)
+    # One timed frame in 32 carries the Lighting event pair (two records: ~10 us of queue time); a short run (the driver's
+    # --steps 20) takes two samples. What a record costs is measured OUTSIDE the timed region (calibration frames below).
+    # (the two records of a sampled frame cost ~10 us of queue time: one frame in 32 keeps that under 0.4 % of the frame rate)
+    light_every = 32 if args.steps >= 256 else (8 if args.steps >= 64 else max(2, (args.steps + 1) // 2))
 
     from collections import deque
     pace_marks = deque()

@@ -708,7 +708,7 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 // HDR store flavour: 0 plain, 1 nontemporal (nt), 2 write-through (sc1): what the launch leaves dirty in L2 is written back
 // at its end, on the critical path of the next launch.
 #ifndef UR_HDR_STORE
-#define UR_HDR_STORE 0
+#define UR_HDR_STORE 2 // write-through: in a loop of its own the launch takes the same time (74.5 / 74.9 / 75.1 us), but the NEXT launch of the frame starts 0.6-0.9 us earlier (frame 80.0-80.4 -> 79.4-79.6 us, four same-box pairs; nt: 79.5-79.8)
 #endif
 // 1: the shadow taps are the FIRST gathers of an iteration (they need only the pixel's position and depth and the wave's
 // lit flag), so that their filter - the first consumer of any gather - finds them landed
@@ -727,13 +727,15 @@ __device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint
 {
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const u32x2_t v = {lo, hi};
+#if UR_HDR_STORE == 2
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(byte_offset), "v"(v), "s"(base) : "memory");
+#else
     UR_GLOBAL u32x2_t* dst = reinterpret_cast<UR_GLOBAL u32x2_t*>((UR_GLOBAL char*)base + byte_offset);
 #if UR_HDR_STORE == 1
     __builtin_nontemporal_store(v, dst);
-#elif UR_HDR_STORE == 2
-    asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(byte_offset), "v"(v), "s"(base) : "memory");
 #else
     *dst = v;
+#endif
 #endif
 }
 
