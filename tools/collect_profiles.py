@@ -13,12 +13,14 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 tag, out = sys.argv[1], sys.argv[2]
-stats = glob.glob(str(ROOT / f"gpurun_out/prof_{tag}_trace/**/*kernel_stats.csv"), recursive=True)
+import os
+newest = lambda pattern: sorted(glob.glob(str(ROOT / pattern), recursive=True), key=os.path.getmtime)[-1:]  # a tag re-run leaves older files behind
+stats = newest(f"gpurun_out/prof_{tag}_trace/**/*kernel_stats.csv")
 assert stats, "no kernel_stats.csv"
 shutil.copy(stats[0], ROOT / f"profiles/{out}_kernel_stats.csv")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind in ("fetch", "write"):
-    for f in glob.glob(str(ROOT / f"gpurun_out/prof_{tag}_{kind}/**/*counter_collection.csv"), recursive=True):
+    for f in newest(f"gpurun_out/prof_{tag}_{kind}/**/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
