@@ -21,9 +21,11 @@ ring = 4
 sets = [dict(A=to_device(g.A), B=to_device(g.B), C=to_device(g.C), D=to_device(g.depth), hdr=to_device(g.hdr)) for _ in range(ring)]
 lay = HzbLayout(W, H)
 hzb = torch.zeros(lay.total, device="cuda")
+import os
+BAND = int(os.environ.get("BAND", H))  # rows of the frame this "rank" shades (the HZB is always the whole frame's)
 def light(k):
     s = sets[k % ring]
-    hp.deferred_lighting_sky(fc.scene, fc.sky, s["A"], s["B"], s["C"], s["D"], tables, s["hdr"], W, H)
+    hp.deferred_lighting_sky(fc.scene, fc.sky, s["A"][:BAND], s["B"][:BAND], s["C"][:BAND], s["D"][:BAND], tables, s["hdr"][:BAND], W, H, 0, BAND)
 def both(k):
     hp.build_hzb(sets[k % ring]["D"], hzb, lay)
     light(k)
@@ -34,7 +36,7 @@ def run(fn, n=400, warm=300):
     for k in range(n): fn(k)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / n
-tag = sys.argv[1] if len(sys.argv) > 1 else ''
+tag = (sys.argv[1] if len(sys.argv) > 1 else '') + f" band={BAND}"
 print(tag, "lighting alone            %.1f us" % run(light))
 for mode, name in ((0, "separate launches (3)"), (1, "tail rides (2 launches)"), (2, "whole chain rides (1)")):
     hp.defer_hzb_tail(mode)

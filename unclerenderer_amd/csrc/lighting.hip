@@ -553,8 +553,8 @@ constexpr uint32_t kLdsWork = 1024 + 17 * 32 + kLdsIrrBytes;        // [0] the w
 constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
 static_assert(6 * 16 * 16 <= 6 * 9 * 64, "both irradiance table forms fit the region");
 constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradiance mip (N <= 2): 6 * 4 * 4 texels, or 6 * 3 * 3 cells of 64 B (UR_TRIM & 1)
-constexpr uint32_t kLdsHzb = kLdsWork + 16;            // 80 floats: mip-2 / mip-3 scratch of the wave that walks HZB pieces
-constexpr uint32_t kLdsLut = kLdsHzb + 80 * 4;                      // (kLutW + 2) x (kLutH + 2) float2
+constexpr uint32_t kLdsHzb = kLdsWork + 16;                         // 80 floats per wave: mip-2 / mip-3 scratch of the waves that walk HZB pieces
+constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
 static_assert(kLdsTiles % 16 == 0, "tile buffers are 16-byte aligned");
@@ -745,10 +745,14 @@ __device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint
 struct HzbRide {
     ur::HzbDispatch d;
     uint32_t grid_x, pieces; // pieces == 0: nothing rides
+    uint32_t walkers;        // how many waves of a workgroup walk pieces: 1 (the last one) when the band is long - the others shade
+                             // meanwhile -, 16 when it is short - the chain must not outlast the shading (informative: the kernel
+                             // instantiation, RIDE_ALL, carries the choice)
+    uint32_t pad;
     uint32_t* done;          // [0] arrivals (reset by the tail workgroup), [1] sticky flag: the tail gave up waiting
 };
 
-template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
+template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB, bool RIDE_ALL>
 __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p, ur::HzbTail hzbTail, HzbRide hzbRide)
 {
     constexpr int kAbl = UR_ABLATE;
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     }
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
-        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline)
+        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
 #if UR_TRIM & 1
         if (threadIdx.x < irrCount) {
@@ -909,34 +913,45 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    // ---- a held-back HZB chain's wide launch rides along: this workgroup's pieces, by its last wave, before the tile loop.
-    //      Memory-bound work beside fifteen waves of compute-bound shading; the chain is complete long before the launch is.
+    // ---- a held-back HZB chain's wide launch rides along: this workgroup's pieces g, g + groups, ... before the tile loop,
+    //      dealt over its last `walkers` waves. The waves that walk none join the tile loop at once and the LDS work counter
+    //      hands the walkers' share of tiles to them. ONE walker when the band is long (a whole 4K frame: fifteen waves shade
+    //      beside it, frame 78.8 us; with all sixteen walking 81.0: the chain's loads then compete with every wave's first
+    //      tiles), all of them when it is short (a 1/8 band: 22.8 against 37.8 us with one walker).
+    //      (RIDE_ALL is a template parameter: with the number of walkers a run-time value the loop spills.)
     if constexpr (WPB == 16) {
-        if (wave == WPB - 1u) { // uniform
+        if (RIDE_ALL || wave == WPB - 1u) { // uniform
             auto ka = __builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             typedef const __attribute__((address_space(4))) HzbRide* KRide;
             const KRide ride = (KRide)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams) + sizeof(ur::HzbTail));
             const uint32_t pieces = ride->pieces;
             if (pieces != 0u) {
-                float* sh2 = reinterpret_cast<float*>(smem + kLdsHzb);
-                const uint32_t gx = ride->grid_x, step = p.hot.groups;
-                for (uint32_t piece = blockIdx.x; piece < pieces; piece += step) { // uniform
+                const uint32_t gx = ride->grid_x, groups = p.hot.groups;
+                float* sh2 = reinterpret_cast<float*>(smem + kLdsHzb) + (RIDE_ALL ? wave * 80u : 0u);
+                const uint32_t first = RIDE_ALL ? blockIdx.x + (WPB - 1u - wave) * groups : blockIdx.x, step = RIDE_ALL ? groups * WPB : groups;
+                for (uint32_t piece = first; piece < pieces; piece += step) { // uniform
                     const uint32_t by = piece / gx, bx = piece - by * gx;
                     ur::hzb_wide_piece_by_one_wave<true>(ride->d, bx, by, lane, sh2, sh2 + 64);
                 }
-                // producer side of the hand-off: mip 4 was stored write-through (sc1); this wave's stores drained, then ONE
-                // arrival. (A release fence instead would write back everything the lighting waves have dirtied in this
-                // XCD's L2: measured, it made the launch 17 us longer.)
+                // producer side of the hand-off: mip 4 was stored write-through (sc1); the wave's stores drained, then ONE
+                // arrival per workgroup. (A release fence instead would write back everything the lighting waves have dirtied
+                // in this XCD's L2: measured, it made the launch 10 us longer.)
 #if UR_RIDE_RELEASE_FENCE
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // ONE arrival per workgroup: a single-lane device-scope add (agent scope is the default for global atomics on
-                // gfx950). Written as an instruction with EXEC narrowed to lane 0: the same statement as C++ under `if (lane
-                // == 0)` makes hipcc keep the loop's LDS-DMA destination (an SGPR operand of inline asm) in a VGPR.
-                {
+                bool signals = true;
+                if (RIDE_ALL) { // every wave counts itself in LDS behind its drained stores; the one that completes the count signals
+                    uint32_t before = 0;
+                    if (lane == 0) before = __hip_atomic_fetch_add(work + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    signals = __builtin_amdgcn_readfirstlane(before) == WPB - 1u;
+                }
+                // A single-lane device-scope add (agent scope is the default for global atomics on gfx950), written as an
+                // instruction with EXEC narrowed to lane 0: the same statement as C++ under `if (lane == 0)` makes hipcc keep the
+                // loop's LDS-DMA destination (an SGPR operand of inline asm) in a VGPR.
+                if (signals) { // uniform
                     uint64_t keep_exec;
                     const uint32_t zero = 0u, one = 1u;
                     uint32_t* done = ride->done;
@@ -1348,6 +1363,7 @@ constexpr size_t kStampWaves = 8192;
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk is filled in here */)
 {
+    typedef void (*kernel_t)(LightingParams, ur::HzbTail, HzbRide);
 #ifdef UR_STAMPS
     if (!g_stamps) UR_HIP_TRY(hipMalloc(&g_stamps, kStampWaves * 16 * sizeof(unsigned long long)));
     UR_HIP_TRY(hipMemsetAsync(g_stamps, 0, kStampWaves * 16 * sizeof(unsigned long long), ctx->stream));
@@ -1355,14 +1371,9 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
 #endif
     constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
     p.timeline = ur::next_timeline_pair(ctx);
-    auto kern = lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB>;
     // MaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: one flag per instantiation and device
-    static bool attr_set[64] = {};
+    static bool attr_set[2][64] = {};
     const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : -1;
-    if (dev < 0 || !attr_set[dev]) {
-        UR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev >= 0) attr_set[dev] = true;
-    }
     StreamHot& h = p.hot;
     h.tilesX = p.W / 16u;
     h.numTiles = h.tilesX * ((p.rows + 3u) / 4u);
@@ -1385,6 +1396,17 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
             ride.grid_x = ctx->pending_wide_grid_x;
             ride.pieces = ctx->pending_wide_grid_x * ctx->pending_wide_grid_y;
             ride.done = ctx->hzb_done;
+            // walkers: the chain should be done within about a quarter of the shading (a piece is ~3 us of one wave's time, a
+            // tile ~1.75 us): walkers >= 7 x pieces-per-workgroup / tiles-per-wave, rounded up to a power of two
+            {
+                static const int forced = env_int("UR_RIDE_WALKERS", 0);
+                const uint32_t lighting_groups = std::max(1, cus - 1 - leave_cus);
+                const double per_group = (double)ride.pieces / lighting_groups, tiles_per_wave = (double)h.numTiles / (lighting_groups * WPB);
+                uint32_t wk = 1;
+                while (wk < (uint32_t)WPB && (double)wk * tiles_per_wave < 7.0 * per_group) wk *= 2;
+                if (forced >= 1) wk = (uint32_t)forced;
+                ride.walkers = wk >= 4u ? (uint32_t)WPB : 1u; // two instantiations: the last wave alone, or all of them
+            }
             ctx->hzb_wide_pending = false;
         }
     } else if (ctx->hzb_wide_pending) { // cannot ride (12-wave build, tiny device): the ordinary launches, in front
@@ -1397,6 +1419,13 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
     static const int chunk_shift = env_int("UR_LIGHTING_CHUNK_SHIFT", 2); // 4K: chunks of 16 / 4 / 1 tiles -> 75.4 / 74.6 / 79.1 us
     h.chunkShift = (uint32_t)std::min(std::max(chunk_shift, 0), 4);
+    const bool ride_all = ride.pieces != 0u && ride.walkers > 1u;
+    const kernel_t kern = ride_all ? static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, true>)
+                                   : static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, false>);
+    if (dev < 0 || !attr_set[ride_all][dev]) {
+        UR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0) attr_set[ride_all][dev] = true;
+    }
     hipLaunchKernelGGL(kern, dim3(groups + (carry_tail ? 1u : 0u)), dim3(64 * WPB), lds, ctx->stream, p, tail, ride);
     return UR_OK;
 }
