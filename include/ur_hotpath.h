@@ -146,7 +146,7 @@ int ur_defer_hzb_tail(ur_ctx* ctx, int mode /* 0 off, 1 tail, 2 whole chain */);
 int ur_flush(ur_ctx* ctx);
 /* Debug: a GPU-side timeline of the context's launches. device_pairs: capacity_pairs x 2 uint64 in device memory, every pair
  * initialised by the caller to {~0, 0}. From then on each cull launch and each streaming Lighting launch on the context takes
- * the next pair (ring) and folds the constant 100 MHz clock (s_memrealtime) into it: [0] = first workgroup's entry, [1] = last
+ * the next pair (until the array is full) and folds the constant 100 MHz clock (s_memrealtime) into it: [0] = first workgroup's entry, [1] = last
  * workgroup's exit. Gaps between consecutive launches are then read off without a profiler (bench.py --timeline). NULL
  * switches it off (the default: the kernels then execute one scalar branch for it). */
 int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t capacity_pairs);

@@ -319,3 +319,38 @@ def test_debug_timeline_orders_the_launches(hotpath):
     hotpath.cull_indirect_args(consts, bounds, None, None, d_args)
     torch.cuda.synchronize()
     assert torch.equal(pairs, before)
+
+
+@pytest.mark.parametrize("rows,row0", [(270, 810), (540, 0)])
+def test_whole_chain_rides_with_a_short_band(hotpath, rows, row0):
+    """A rank that shades a 1/8 or 1/4 band of the 4K frame still builds the WHOLE frame's HZB: the chain would outlast the
+    shading if one wave per workgroup walked its pieces, so every wave does (the RIDE_ALL instantiation). Same bits."""
+    import torch
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    w, h = 3840, 2160
+    fc0, g0, tables, lay0, dev0 = _setup(hotpath, 512, 256)
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=128, env_mip_count=5)
+    g = synth.gbuffer_iid(w, h, 9)
+    lay = HzbLayout(w, h)
+    sl = slice(row0, row0 + rows)
+    A, B, Cc, D_full = to_device(g.A[sl]), to_device(g.B[sl]), to_device(g.C[sl]), to_device(g.depth)
+    D_band = D_full[sl]
+    ref_hzb = torch.full((lay.total,), -1.0, device="cuda")
+    ref_hdr = to_device(g.hdr[sl])
+    hotpath.build_hzb(D_full, ref_hzb, lay)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, A, B, Cc, D_band, tables, ref_hdr, w, h, row0, rows)
+    torch.cuda.synchronize()
+    hotpath.defer_hzb_tail(2)
+    try:
+        for it in range(2):
+            hzb = torch.full((lay.total,), -1.0, device="cuda")
+            hdr = to_device(g.hdr[sl])
+            hotpath.build_hzb(D_full, hzb, lay)
+            torch.cuda.synchronize()
+            assert float(hzb[0]) == -1.0
+            hotpath.deferred_lighting_sky(fc.scene, fc.sky, A, B, Cc, D_band, tables, hdr, w, h, row0, rows)
+            torch.cuda.synchronize()
+            assert torch.equal(hzb, ref_hzb) and torch.equal(hdr, ref_hdr), it
+    finally:
+        hotpath.defer_hzb_tail(0)

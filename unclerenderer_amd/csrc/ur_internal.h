@@ -42,7 +42,7 @@ struct ur_ctx {
     bool hzb_wide_pending = false;
     ur::HzbDispatch pending_wide{};
     uint32_t pending_wide_grid_x = 0, pending_wide_grid_y = 0;
-    // ur_debug_timeline: device ring of {first entry, last exit} pairs in s_memrealtime ticks (100 MHz), one pair per cull and per
+    // ur_debug_timeline: device array of {first entry, last exit} pairs in s_memrealtime ticks (100 MHz), one pair per cull and per
     // streaming Lighting launch, in launch order (the caller initialises every pair to {~0, 0})
     unsigned long long* timeline = nullptr;
     uint32_t timeline_cap = 0, timeline_pos = 0;
@@ -75,8 +75,8 @@ enum { UR_MODE_LIGHTING = 0, UR_MODE_SKY = 1, UR_MODE_FUSED = 2 };
 // the next {entry, exit} pair of the debug timeline (nullptr when it is off)
 inline unsigned long long* next_timeline_pair(ur_ctx* ctx)
 {
-    if (!ctx->timeline || ctx->timeline_cap == 0) return nullptr;
-    return ctx->timeline + 2u * (size_t)(ctx->timeline_pos++ % ctx->timeline_cap);
+    if (!ctx->timeline || ctx->timeline_pos >= ctx->timeline_cap) return nullptr; // full: later launches stamp nothing
+    return ctx->timeline + 2u * (size_t)ctx->timeline_pos++;
 }
 // launches a deferred HZB tail on its own if one is pending (ur_flush and every launch that reads or rewrites the HZB)
 int flush_hzb_tail(ur_ctx* ctx);
