@@ -548,9 +548,13 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
     med, mn = _time_events(torch, lambda: hp.cull_indirect_args(consts, bounds, hzb8, lay8, d_args, None, d_vis, d_cnt), 50)
     f_frustum = 1.0 - frustum_culled / n
     cull_bytes = n * (36 + 16 * f_frustum) + 4 * visible
+    # SURVEY.md section 8d asks for both accountings: the algorithmic 4 B per InstanceCount word, and the 64-byte line each of those
+    # words is alone in (FIndirectDrawCommand stride 64: the layout is the reference's, the write amplification comes with it)
+    line_bytes = n * (32 + 64 + 16 * f_frustum) + 4 * visible
     out["cull_1m"] = {"instances": n, "visible": visible, "frustum_culled": frustum_culled, "occluded": occluded,
                       "median_us": med * 1e6, "instances_per_s": n / med, "algorithmic_GBps": cull_bytes / med / 1e9,
-                      "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS}
+                      "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS,
+                      "with_64B_store_lines_GBps": line_bytes / med / 1e9, "frac_hbm_with_64B_store_lines": line_bytes / med / 1e9 / HBM_PEAK_GBS}
     # ---- fused Lighting+Sky on the other G-buffers the contract names: the independent-per-pixel generator
     #      at the frame size (the stress case: every lane gathers its own cube / LUT / shadow line), C2's 1920x1080 and C5's
     #      7680x4320, Sponza constants, shipped IBL tables. Back-to-back launches over cold buffer sets between ONE event pair.
