@@ -543,16 +543,15 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
 //    t+1's gathers is a vmcnt(0) by construction (hipcc sees nothing younger), which also retires the DMA for tile t+2
 //    one full iteration after its issue — before iteration t+2 reads it. No counted waits, no barriers in the loop.
 //  * The BRDF LUT lives in LDS as bordered fp32 pairs (clamp addressing = border texels; one med3 instead of eight
-//    min/max, no unpack/convert per tap), the launch-uniform irradiance mip as fp32 texels, the sRGB table as before.
+//    min/max, no unpack/convert per tap), the launch-uniform irradiance mip as per-cell fp32 polynomials, the sRGB table as before.
 //  * The shadow transform of the (orthographic) light is folded on the host into three affine forms of the camera ray.
 // =====================================================================================================================
 constexpr uint32_t kLutW = 128, kLutH = 32, kLutE = kLutW + 2;    // streaming kernel: LUT dimensions are compile-time
 constexpr uint32_t kLdsSrgb = 0;                                    // 256 floats
-constexpr uint32_t kLdsIrrBytes = 6 * 9 * 64;                       // the larger of the two table forms (6 * 16 texels * 16 B = 1536; 54 cells * 64 B)
+constexpr uint32_t kLdsIrrBytes = 6 * 9 * 64;                       // 54 cells x 64 B
 constexpr uint32_t kLdsWork = 1024 + 17 * 32 + kLdsIrrBytes;        // [0] the workgroup's tile counter, [1] waves that left the loop (16 bytes reserved)
 constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
-static_assert(6 * 16 * 16 <= 6 * 9 * 64, "both irradiance table forms fit the region");
-constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradiance mip (N <= 2): 6 * 4 * 4 texels, or 6 * 3 * 3 cells of 64 B (UR_TRIM & 1)
+constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradiance mip (N <= 2) as per-cell polynomials: up to 6 * 3 * 3 cells of 64 B
 constexpr uint32_t kLdsHzb = kLdsWork + 16;                         // 80 floats per wave: mip-2 / mip-3 scratch of the waves that walk HZB pieces
 constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
@@ -710,16 +709,6 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 #ifndef UR_HDR_STORE
 #define UR_HDR_STORE 2 // write-through: in a loop of its own the launch takes the same time (74.5 / 74.9 / 75.1 us), but the NEXT launch of the frame starts 0.6-0.9 us earlier (frame 80.0-80.4 -> 79.4-79.6 us, four same-box pairs; nt: 79.5-79.8)
 #endif
-// 1: the shadow taps are the FIRST gathers of an iteration (they need only the pixel's position and depth and the wave's
-// lit flag), so that their filter - the first consumer of any gather - finds them landed
-#ifndef UR_SHADOW_FIRST
-#define UR_SHADOW_FIRST 0
-#endif
-// bit 0: the LDS irradiance table holds, per bilinear CELL, the polynomial a + b fx + c fy + d fx fy of each channel (one
-// 64-byte entry, three ds_read_b128, ten VALU instructions) instead of texels (four reads, seventeen instructions)
-#ifndef UR_TRIM
-#define UR_TRIM 1
-#endif
 #ifndef UR_RIDE_RELEASE_FENCE
 #define UR_RIDE_RELEASE_FENCE 0 // diagnostic: the producer side of the riding HZB hand-off as plain stores + an agent-scope release fence
 #endif
@@ -824,17 +813,12 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     const float sv = threadIdx.x < 256u ? p.srgb[threadIdx.x] : 0.0f;
     half4_t ih = {}, ih10 = {}, ih01 = {}, ih11 = {};
     const uint32_t irrE = p.irrN0 + 2u;
-#if UR_TRIM & 1
     const uint32_t irrC = p.irrN0 + 1u, irrCount = IRR_LDS ? 6u * irrC * irrC : 0u; // cells: <= 54
     if (threadIdx.x < irrCount) {
         const uint32_t f = threadIdx.x / (irrC * irrC), r = threadIdx.x - f * irrC * irrC, cj = r / irrC, ci = r - cj * irrC;
         const uint32_t t0 = p.irrOffset0 + (f * irrE + cj) * irrE + ci;
         ih = p.env[t0]; ih10 = p.env[t0 + 1u]; ih01 = p.env[t0 + irrE]; ih11 = p.env[t0 + irrE + 1u];
     }
-#else
-    const uint32_t irrCount = IRR_LDS ? 6u * irrE * irrE : 0u; // <= 96
-    if (threadIdx.x < irrCount) ih = p.env[p.irrOffset0 + threadIdx.x];
-#endif
     // Tile schedule: chunks of 2^cs consecutive tiles are dealt round-robin to the workgroups (chunks of 4: the per-workgroup
     // work then differs by +-3 %; with 16 the image content makes it +-9 %, with 1 the DRAM locality of a row is lost),
     // dynamically inside a workgroup: a wave takes its next tile from a counter in LDS. The SIMD's oldest-first
@@ -877,7 +861,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     {
         if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
-#if UR_TRIM & 1
         if (threadIdx.x < irrCount) {
             // value(fx, fy) = t00 + (t10 - t00) fx + (t01 - t00) fy + (t11 - t10 - t01 + t00) fx fy, per channel
             const float a[3] = {(float)ih.x, (float)ih.y, (float)ih.z}, b[3] = {(float)ih10.x, (float)ih10.y, (float)ih10.z};
@@ -885,9 +868,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 #pragma unroll
             for (int k = 0; k < 3; ++k) irrT[threadIdx.x * 4u + k] = float4a{a[k], b[k] - a[k], c[k] - a[k], (d[k] - b[k]) - (c[k] - a[k])};
         }
-#else
-        if (threadIdx.x < irrCount) irrT[threadIdx.x] = float4a{(float)ih.x, (float)ih.y, (float)ih.z, 0.0f};
-#endif
         if (threadIdx.x < 17u) {
             const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
             const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
@@ -1022,31 +1002,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const float spec0 = h2f_lo(gb.x), metallic = h2f_hi(gb.x), roughness = h2f_lo(gb.y);
             const F3 L = f3(p.hot.Lw[0], p.hot.Lw[1], p.hot.Lw[2]);
             const float NdotL = sat(dot(N, L));
-#if UR_SHADOW_FIRST
-            // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF (direct = 0).
-            const bool wave_direct = __any(NdotL > 0.0f);
-            const bool wave_lit = SHADOWS && wave_direct;
-            f32x3_t sa = {0, 0, 0}, sb = {0, 0, 0}, sc3 = {0, 0, 0};
-            float xa = 0.0f, ya = 0.0f, cmp = 0.0f, sfx = 0.0f, sfy = 0.0f;
-            bool fast = true;
-            if (wave_lit) {
-                // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) = viewZ * (affine in ndc) + constant
-                xa = fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), shT[0]);
-                ya = fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), shT[1]);
-                cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), shT[2]);
-                const float xa0 = floorf(xa), ya0 = floorf(ya);
-                sfx = xa - xa0; sfy = ya - ya0;
-                // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
-                const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, p.hot.shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, p.hot.shadowHm3);
-                fast = ic == xa0 && jc == ya0;
-                const uint32_t o0 = (uint32_t)fmaf(jc, p.hot.shadowWf, ic) * 4u, o1 = o0 + p.hot.shadowRowBytes, o2 = o1 + p.hot.shadowRowBytes;
-                const float* smap = p.hot.shadow;
-                sa = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o0);
-                sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
-                sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             const F3 Wd = f3(fmaf(ndcx, p.hot.WA[0], fmaf(ndcy, p.hot.WB[0], WC[0])), fmaf(ndcx, p.hot.WA[1], fmaf(ndcy, p.hot.WB[1], WC[1])),
                              fmaf(ndcx, p.hot.WA[2], fmaf(ndcy, p.hot.WB[2], WC[2]))); // (ra, rb, 1) * ViewInverse3x3
             // V = normalize(-viewPos) = -sign(viewZ) Wd / |Wd|; sign(-viewZ) is the stored sign of A.w
@@ -1103,7 +1058,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 pia = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 pib = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + p.hot.irrRowBytes));
             }
-#if !UR_SHADOW_FIRST
             // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF (direct = 0).
             const bool wave_direct = __any(NdotL > 0.0f);
             const bool wave_lit = SHADOWS && wave_direct;
@@ -1126,7 +1080,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
                 sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
             }
-#endif
             UR_STAMP(tB);
             // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
             // table byte offsets straight from the packed texel: (c << 2) & 0x3FC, (c >> 6) & 0x3FC, (c >> 14) & 0x3FC
@@ -1153,24 +1106,15 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
                 const float fx = x - i0, fy = y - j0;
-#if UR_TRIM & 1
-                // cell (i0, j0) of the face: irrEf / irrEEf hold N + 1 and (N + 1)^2 in this build
+                // bilinear CELL (i0, j0) of the face (irrEf / irrEEf hold N + 1 and (N + 1)^2 when the table is in LDS): the polynomial
+                // a + b fx + c fy + d fx fy of each channel - one 64-byte entry, three ds_read_b128, ten VALU instructions (as
+                // texels: four reads, seventeen instructions; 74.3 -> 73.6 us)
                 const float4a* t = irrT + 4u * (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
                 const float4a cx = t[0], cy = t[1], cz = t[2];
                 const float fxy = fx * fy;
                 irradiance.x = fmaf(cx.w, fxy, fmaf(cx.z, fy, fmaf(cx.y, fx, cx.x)));
                 irradiance.y = fmaf(cy.w, fxy, fmaf(cy.z, fy, fmaf(cy.y, fx, cy.x)));
                 irradiance.z = fmaf(cz.w, fxy, fmaf(cz.z, fy, fmaf(cz.y, fx, cz.x)));
-#else
-                const uint32_t E = p.hot.irrN0 + 2u;
-                const float4a* t = irrT + (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
-                const float4a t00 = t[0], t10 = t[1], t01 = t[E], t11 = t[E + 1];
-                const float wy0 = 1.0f - fy;
-                const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
-                irradiance.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
-                irradiance.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
-                irradiance.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00 * t00.z)));
-#endif
             }
             // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) ----------------------------------------
             const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
@@ -1611,9 +1555,7 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
             h.envMaxLevel = (float)(p.envMips - 1u);
             const uint32_t iE = p.irrN0 + 2u;
             h.irrN0 = p.irrN0; h.irrNf = (float)p.irrN0; h.irrEf = (float)iE; h.irrEEf = (float)(iE * iE);
-#if UR_TRIM & 1
             if (p.irrN0 <= 2u) { h.irrEf = (float)(p.irrN0 + 1u); h.irrEEf = (float)((p.irrN0 + 1u) * (p.irrN0 + 1u)); } // LDS table of cells
-#endif
             h.irrOfff = (float)p.irrOffset0; h.irrRowBytes = iE * 8u;
             h.env = p.env; h.hdr = p.hdr;
             for (int k = 0; k < 9; ++k) h.R[k] = p.R[k];
