@@ -45,7 +45,7 @@ def main():
     want = argv[2] if len(argv) > 2 else "lighting_stream_kernelILi2ELb1ELb1ELi16E"
     lines = open(path).read().splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and want in l and ":" in l)
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))  # (the kernel has early exits: not the first s_endpgm)
     body = lines[start:end + 1]
     lo, hi = 0, len(body)
     if len(argv) > 3:

@@ -555,7 +555,24 @@ constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradianc
 constexpr uint32_t kLdsHzb = kLdsWork + 16;                         // 80 floats per wave: mip-2 / mip-3 scratch of the waves that walk HZB pieces
 constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
+// Diagnostic / candidate structure: 1 = producer-consumer wave specialisation. The LAST wave of a workgroup is a LOADER: it does
+// nothing but stream the workgroup's tiles, in claim order, into a ring of 48 two-KB slots in LDS (24 tiles = 48 DMAs in flight),
+// publishing a slot in `ready[]` once the counted vmcnt says its tile has landed and refilling it once `done[]` says its reader
+// is through. The other fifteen waves shade: they claim a sequence number, wait for that slot, read it, release it, and never
+// issue a DMA (their in-order vmcnt queue holds gathers and the store only).
+#ifndef UR_LOADER_WAVE
+#define UR_LOADER_WAVE 0
+#endif
+#ifndef UR_LOADER_VMCNT
+#define UR_LOADER_VMCNT 48 // DMA instructions the loader leaves in flight when it publishes a chunk: 8 per chunk of four tiles
+#endif
+#ifndef UR_LOADER_PRIO
+#define UR_LOADER_PRIO 3
+#endif
+#define UR_STR2(x) #x
+#define UR_STR(x) UR_STR2(x)
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
+[[maybe_unused]] constexpr uint32_t kRingChunks = 14, kRingSlots = 4 * kRingChunks, kRingChunksInFlight = UR_LOADER_VMCNT / 8 + 1; // UR_LOADER_WAVE: the workgroup's tile ring in chunks of four tiles, chunks the loader keeps in flight
 static_assert(kLdsTiles % 16 == 0, "tile buffers are 16-byte aligned");
 
 __device__ __forceinline__ uint32_t lds_address(const void* p)
@@ -609,10 +626,8 @@ __device__ __forceinline__ TileSrc tile_src(P p, uint32_t lane, uint32_t maxRow)
 
 // Both DMA instructions of a tile in one statement, one M0 set-up: the instruction offset (1024) moves the global AND the
 // LDS address of the second one, so its source pointer is biased by -1024.
-__device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pixel index of the tile's first pixel*/, uint32_t lds_dst)
+__device__ __forceinline__ void tile_dma_at(const char* g1, const char* g2 /* biased by -1024 */, uint32_t lds_dst)
 {
-    const char* g1 = s.p1 + (uint64_t)origin * 8u;
-    const char* g2 = s.p2 + (uint64_t)origin * s.mul2 - 1024;
     uint32_t keep;
     // nontemporal hint (UR_DMA_NT): 1 = both instructions, 2 = the A|B one only (the other carries the depth rows, which a riding
     // Build HZB reads a second time in the same launch)
@@ -631,6 +646,12 @@ __device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pix
                  : "=&s"(keep)
                  : "v"(g1), "v"(g2), "s"(lds_dst)
                  : "memory");
+}
+__device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pixel index of the tile's first pixel*/, uint32_t lds_dst)
+{
+    const char* g1 = s.p1 + (uint64_t)origin * 8u;
+    const char* g2 = s.p2 + (uint64_t)origin * s.mul2 - 1024;
+    tile_dma_at(g1, g2, lds_dst);
 }
 
 // tile (tx, ty) -> LDS; `full` = the precomputed per-lane sources of a whole tile
@@ -841,7 +862,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 
 
     UR_STAMP(tP1);
+#if !UR_LOADER_WAVE
     if (have0) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
+#endif
     UR_STAMP(tP2);
     // per-lane part of the pixel's NDC (the tile origin is added per iteration), and the few uniforms that appear as the
     // SECOND scalar operand of an FMA
@@ -859,7 +882,10 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     }
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
-        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
+        if (threadIdx.x == 0) { work[0] = UR_LOADER_WAVE ? 0u : 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
+#if UR_LOADER_WAVE
+        if (threadIdx.x < 2u * kRingSlots) reinterpret_cast<uint32_t*>(smem + kLdsTiles + kRingSlots * kTileBytes)[threadIdx.x] = 0u; // ready[48], done[48]
+#endif
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
         if (threadIdx.x < irrCount) {
             // value(fx, fy) = t00 + (t10 - t00) fx + (t01 - t00) fy + (t11 - t10 - t01 + t00) fx fy, per channel
@@ -886,12 +912,74 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     // The second static tile goes out behind the barrier, i.e. behind every first tile of the workgroup: the start-up burst
     // (2 KB per wave and tile, 8 MB over the chip) that the first iteration has to wait for is halved, the other half
     // lands under the first iteration's arithmetic. Its two DMA instructions may stay in flight here.
+#if !UR_LOADER_WAVE
     if (have0 && tile1 < p.hot.numTiles) {
         tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t* const ringReady = reinterpret_cast<uint32_t*>(smem + kLdsTiles + kRingSlots * kTileBytes);
+    uint32_t* const ringDone = ringReady + kRingSlots;
+    if (wave == WPB - 1u) {
+        // ---- the loader: chunk k = the workgroup's k-th group of four consecutive tiles (claims 4k .. 4k + 3) -> slots (4k .. 4k + 3) % 56.
+        //      One wave issues an instruction every five cycles or so at best, and the 330 cycles a tile may take at 8 TB/s are few:
+        //      the schedule, the slot hand-shake and the address arithmetic are per CHUNK (one ds_read_b128 of four `done` words,
+        //      one ds_write_b128 of four `ready` words), a tile costs two 64-bit adds, an M0 write and its two DMA instructions.
+        typedef __attribute__((address_space(3))) volatile u32x4_t* LdsV4; // (a volatile access through a generic pointer is a FLAT instruction, which counts in vmcnt)
+        __builtin_amdgcn_s_setprio(UR_LOADER_PRIO);
+        const KParams kpl = fresh_params();
+        const uint32_t ringBase = __builtin_amdgcn_readfirstlane(lds_address(smem + kLdsTiles));
+        const uint32_t step2 = 16u * src.mul2;
+        uint32_t k = 0;
+        for (;; ++k) { // uniform
+            const uint32_t t0 = k * chunkStride + base;
+            if (t0 >= p.hot.numTiles) break;
+            const uint32_t n = min(4u, p.hot.numTiles - t0), slot0 = (k % kRingChunks) * 4u;
+            if (k >= kRingChunks) { // the chunk's slots: their previous occupants (chunk k - 14) must have been read
+                const uint32_t want = (k - kRingChunks) * 4u + 1u;
+                uint32_t spins = 0;
+                for (;;) {
+                    const u32x4_t d = *(LdsV4)(ringDone + slot0);
+                    const bool ok = d.x == want && d.y == want + 1u && d.z == want + 2u && d.w == want + 3u;
+                    if (__builtin_amdgcn_readfirstlane((uint32_t)ok) != 0u) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) break; // (a lost release must not hang the chip)
+                }
+            }
+            const uint32_t ty0 = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)t0 * p.hot.tilesXMagic) >> 32)), tx0 = t0 - ty0 * p.hot.tilesX;
+            if (n == 4u && tx0 + 4u <= p.hot.tilesX && p.hot.rows - ty0 * 4u >= 4u) { // four whole tiles of one tile row
+                const uint32_t origin = (UR_ABLATE & 64) ? 0u : (ty0 * 4u) * p.hot.W + tx0 * 16u;
+                const char* g1 = src.p1 + (uint64_t)origin * 8u;
+                const char* g2 = src.p2 + (uint64_t)origin * src.mul2 - 1024;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    tile_dma_at(g1, g2, ringBase + (slot0 + j) * kTileBytes);
+                    if (!(UR_ABLATE & 64)) { g1 += 128; g2 += step2; }
+                }
+            } else {
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint32_t t = t0 + j;
+                    const uint32_t tyl = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)t * p.hot.tilesXMagic) >> 32)), txl = t - tyl * p.hot.tilesX;
+                    tile_prefetch<MODE>(kpl, p.hot.W, p.hot.rows, src, lane, txl, tyl, ringBase + (slot0 + j) * kTileBytes);
+                }
+            }
+            if (k + 1u >= kRingChunksInFlight) { // all but the youngest 6 chunks (48 DMA instructions) have landed: publish the oldest of the 7
+                if (n == 4u) asm volatile("s_waitcnt vmcnt(" UR_STR(UR_LOADER_VMCNT) ")" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the workgroup's last chunk may hold fewer instructions)
+                const uint32_t c = k + 1u - kRingChunksInFlight, v = c * 4u + 1u;
+                if (lane == 0) *(LdsV4)(ringReady + (c % kRingChunks) * 4u) = u32x4_t{v, v + 1u, v + 2u, v + 3u};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t c = k >= kRingChunksInFlight ? k - kRingChunksInFlight + 1u : 0u; c < k; ++c) {
+            const uint32_t v = c * 4u + 1u;
+            if (lane == 0) *(LdsV4)(ringReady + (c % kRingChunks) * 4u) = u32x4_t{v, v + 1u, v + 2u, v + 3u};
+        }
+    }
+#endif
 
     // ---- a held-back HZB chain's wide launch rides along: this workgroup's pieces g, g + groups, ... before the tile loop,
     //      dealt over its last `walkers` waves. The waves that walk none join the tile loop at once and the LDS work counter
@@ -900,7 +988,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     //      tiles), all of them when it is short (a 1/8 band: 22.8 against 37.8 us with one walker).
     //      (RIDE_ALL is a template parameter: with the number of walkers a run-time value the loop spills.)
     if constexpr (WPB == 16) {
-        if (RIDE_ALL || wave == WPB - 1u) { // uniform
+        constexpr uint32_t kWalkers = UR_LOADER_WAVE ? WPB - 1u : WPB; // (the loader wave walks nothing)
+        if (!(UR_LOADER_WAVE && wave == WPB - 1u) && (RIDE_ALL || wave == kWalkers - 1u)) { // uniform
             auto ka = __builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             typedef const __attribute__((address_space(4))) HzbRide* KRide;
@@ -909,7 +998,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             if (pieces != 0u) {
                 const uint32_t gx = ride->grid_x, groups = p.hot.groups;
                 float* sh2 = reinterpret_cast<float*>(smem + kLdsHzb) + (RIDE_ALL ? wave * 80u : 0u);
-                const uint32_t first = RIDE_ALL ? blockIdx.x + (WPB - 1u - wave) * groups : blockIdx.x, step = RIDE_ALL ? groups * WPB : groups;
+                const uint32_t first = RIDE_ALL ? blockIdx.x + (kWalkers - 1u - wave) * groups : blockIdx.x, step = RIDE_ALL ? groups * kWalkers : groups;
                 for (uint32_t piece = first; piece < pieces; piece += step) { // uniform
                     const uint32_t by = piece / gx, bx = piece - by * gx;
                     ur::hzb_wide_piece_by_one_wave<true>(ride->d, bx, by, lane, sh2, sh2 + 64);
@@ -926,7 +1015,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 if (RIDE_ALL) { // every wave counts itself in LDS behind its drained stores; the one that completes the count signals
                     uint32_t before = 0;
                     if (lane == 0) before = __hip_atomic_fetch_add(work + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    signals = __builtin_amdgcn_readfirstlane(before) == WPB - 1u;
+                    signals = __builtin_amdgcn_readfirstlane(before) == kWalkers - 1u;
                 }
                 // A single-lane device-scope add (agent scope is the default for global atomics on gfx950), written as an
                 // instruction with EXEC narrowed to lane 0: the same statement as C++ under `if (lane == 0)` makes hipcc keep the
@@ -946,6 +1035,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 
     uint32_t parity = 0;
 // (macro: the statement appears in the shading path and in the all-sky path)
+#if UR_LOADER_WAVE
+#define UR_PREFETCH_POINT() do { } while (0)
+#else
 #define UR_PREFETCH_POINT()                                                                                              \
     do {                                                                                                                 \
         if (more1) {                                                                                                     \
@@ -959,10 +1051,36 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
+#endif
 #ifdef UR_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tE2 = 0, tF = 0, tG = 0, sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0, sum5 = 0, sum6 = 0, iters = 0;
     UR_STAMP(tL);
 #endif
+#if UR_LOADER_WAVE
+    // a shading wave: sequence numbers from the counter, one ahead (the LDS atomic's latency hides behind a tile)
+    uint32_t seq = 0, seqNext = 0;
+    if (wave != WPB - 1u) {
+        if (lane == 0) seq = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        seq = __builtin_amdgcn_readfirstlane(seq);
+    }
+    while (wave != WPB - 1u) {
+        tile = (seq >> cs) * chunkStride + base + (seq & cmask);
+        if (tile >= p.hot.numTiles) break;
+        const KParams kp = fresh_params();
+        const bool more1 = true;
+        ty = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)tile * p.hot.tilesXMagic) >> 32)); tx = tile - ty * p.hot.tilesX;
+        if (lane == 0) seqNext = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t slot = seq % kRingSlots;
+        {
+            uint32_t spins = 0;
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ringReady + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq + 1u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) break; // (a lost publication must not hang the chip)
+            }
+            asm volatile("" ::: "memory");
+        }
+        const unsigned char* buf = smem + kLdsTiles + slot * kTileBytes;
+#else
     while (have0) {
         UR_STAMP(tA);
         const KParams kp = fresh_params(); // cold paths re-read what they need (sky constants, shadow slow path, partial tiles)
@@ -973,6 +1091,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         uint32_t claim = 0;
         if (more1 && lane == 0) claim = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned char* buf = myTiles + parity * kTileBytes;
+#endif
         const uint2 ga = *reinterpret_cast<const uint2*>(buf + lane * 8u);          // (nx, ny), (nz, -viewZ)
         const uint2 gb = *reinterpret_cast<const uint2*>(buf + 512u + lane * 8u);   // (specular, metallic), (roughness, 1)
         const uint2 gd = *reinterpret_cast<const uint2*>(buf + 1024u + lane * 8u);  // HDR in
@@ -981,8 +1100,18 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 
         bool sky = false;
         F3 out = f3(0.0f, 0.0f, 0.0f);
+#if UR_LOADER_WAVE
+        const float depthL = MODE == ur::UR_MODE_FUSED ? *reinterpret_cast<const float*>(buf + 1792u + lane * 4u) : 0.0f;
+        // the slot is free once the wave's reads of it have returned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(ringDone + slot, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         if (MODE == ur::UR_MODE_FUSED) {
+#if UR_LOADER_WAVE
+            const float depth = depthL;
+#else
             const float depth = *reinterpret_cast<const float*>(buf + 1792u + lane * 4u);
+#endif
             // no pixel of the frame has a sphere depth above skyDepthMax: a wave of nearer geometry skips the per-pixel test
             if (__any(!(depth > p.hot.skyDepthMax))) {
                 const float vx = ndcx * p.hot.skyInvP11, vy = ndcy * p.hot.nSkyInvP22;
@@ -1172,7 +1301,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             // hipcc has no load of its own in flight here: the DMA for the tile two steps ahead goes into the buffer just read.
             // The vmcnt(0) retires every older vector-memory operation of the wave, in particular the DMA issued at the previous
             // iteration's prefetch point: the tile the NEXT iteration reads is in LDS from here on.
+#if !UR_LOADER_WAVE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             UR_STAMP(tE);
             UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
@@ -1230,7 +1361,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             }
         } else {
             __builtin_amdgcn_sched_barrier(0);
+#if !UR_LOADER_WAVE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1247,10 +1380,15 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         if (tE != 0) { sum0 += tB - tA; sum1 += tC - tB; sum2 += tD - tC; sum3 += tE - tD; sum4 += tF - tE; sum5 += tE2 - tE; sum6 += tF - tG; iters += 1; }
         tE = 0;
 #endif
+#if UR_LOADER_WAVE
+        seq = __builtin_amdgcn_readfirstlane(seqNext);
+        (void)more1; (void)parity; (void)tile1; (void)tx1; (void)ty1;
+#else
         if (!more1) break;
         tile = tile1; tile1 = tile2; // tile2 stays 0xFFFFFFFF when nothing was left to claim
         tx = tx1; ty = ty1; tx1 = tx2; ty1 = ty2;
         parity ^= 1u;
+#endif
     }
 #undef UR_PREFETCH_POINT
     if (p.timeline != nullptr) { // debug timeline: the workgroup's LAST wave to leave the loop stamps the exit (uniform branch)
@@ -1313,7 +1451,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     UR_HIP_TRY(hipMemsetAsync(g_stamps, 0, kStampWaves * 16 * sizeof(unsigned long long), ctx->stream));
     p.stamps = g_stamps;
 #endif
-    constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
+    constexpr uint32_t lds = UR_LOADER_WAVE ? kLdsTiles + kRingSlots * kTileBytes + 2u * kRingSlots * 4u : kLdsTiles + WPB * 2u * kTileBytes;
     p.timeline = ur::next_timeline_pair(ctx);
     // MaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: one flag per instantiation and device
     static bool attr_set[2][64] = {};
@@ -1362,7 +1500,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
     static const int chunk_shift = env_int("UR_LIGHTING_CHUNK_SHIFT", 2); // 4K: chunks of 16 / 4 / 1 tiles -> 75.4 / 74.6 / 79.1 us
-    h.chunkShift = (uint32_t)std::min(std::max(chunk_shift, 0), 4);
+    h.chunkShift = UR_LOADER_WAVE ? 2u : (uint32_t)std::min(std::max(chunk_shift, 0), 4); // (the loader wave moves chunks of four tiles)
     const bool ride_all = ride.pieces != 0u && ride.walkers > 1u;
     const kernel_t kern = ride_all ? static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, true>)
                                    : static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, false>);
