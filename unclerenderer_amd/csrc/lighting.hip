@@ -1512,8 +1512,8 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     return UR_OK;
 }
 
-// One persistent workgroup per CU; waves per SIMD = WPB / 4. Measured at 4K (sustained clocks): 16 -> 76.6 us, 12 -> 80.6 us,
-// 8 -> ~95 us; two workgroups of 10 waves per CU (96 VGPRs) spill.
+// One persistent workgroup per CU; waves per SIMD = WPB / 4. Measured at 4K (sustained clocks), round 1: 16 -> 76.6 us, 12 -> 80.6 us,
+// 8 -> ~95 us; round 2: 16 -> 71.8 us, 12 -> 75.1 us (same box). Two workgroups of 10 waves per CU (96 VGPRs) spill.
 template <int MODE, bool SHADOWS, bool IRR_LDS>
 int launch_stream(ur_ctx* ctx, const LightingParams& p)
 {
