@@ -556,10 +556,12 @@ constexpr uint32_t kLdsHzb = kLdsWork + 16;                         // 80 floats
 constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 // Diagnostic / candidate structure: 1 = producer-consumer wave specialisation. The LAST wave of a workgroup is a LOADER: it does
-// nothing but stream the workgroup's tiles, in claim order, into a ring of 48 two-KB slots in LDS (24 tiles = 48 DMAs in flight),
-// publishing a slot in `ready[]` once the counted vmcnt says its tile has landed and refilling it once `done[]` says its reader
-// is through. The other fifteen waves shade: they claim a sequence number, wait for that slot, read it, release it, and never
-// issue a DMA (their in-order vmcnt queue holds gathers and the store only).
+// nothing but stream the workgroup's tiles, in claim order, into a ring of 56 two-KB slots in LDS (7 chunks of four tiles = 56 DMA
+// instructions in flight), publishing a chunk's slots in `ready[]` once the counted vmcnt says its tiles have landed and refilling
+// them once `done[]` says their readers are through. The other fifteen waves shade: they claim a sequence number, wait for that
+// slot, read it, release it, and never issue a DMA (their in-order vmcnt queue holds gathers and the store only). Measured and
+// not adopted (profiles/r02_ablation.txt block E); kept so that the measurement can be repeated
+// (tools/build_variants.py loader=-DUR_LOADER_WAVE=1; tests/test_isa_guard.py compiles it).
 #ifndef UR_LOADER_WAVE
 #define UR_LOADER_WAVE 0
 #endif
@@ -884,7 +886,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     {
         if (threadIdx.x == 0) { work[0] = UR_LOADER_WAVE ? 0u : 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
 #if UR_LOADER_WAVE
-        if (threadIdx.x < 2u * kRingSlots) reinterpret_cast<uint32_t*>(smem + kLdsTiles + kRingSlots * kTileBytes)[threadIdx.x] = 0u; // ready[48], done[48]
+        if (threadIdx.x < 2u * kRingSlots) reinterpret_cast<uint32_t*>(smem + kLdsTiles + kRingSlots * kTileBytes)[threadIdx.x] = 0u; // ready[56], done[56]
 #endif
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
         if (threadIdx.x < irrCount) {
