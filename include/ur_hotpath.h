@@ -204,7 +204,13 @@ int ur_stage_env_cube(ur_ctx* ctx, const ur_half4* src_host, uint32_t base_size,
  * (ONE/ONE, colour and alpha; DeferredRenderer.cpp:1997-2005) into hdr_inout.
  * gbuf_a: (view normal.xyz, -viewZ) RGBA16F; gbuf_b: (specular, metallic, roughness, 1) RGBA16F;
  * gbuf_c: R8G8B8A8_UNORM_SRGB (R in the low byte); hdr_inout: RGBA16F holding (emissive, 1).
- * Like the reference it shades EVERY pixel, so cleared G-buffer pixels come out NaN. */
+ * Like the reference it shades EVERY pixel, so cleared G-buffer pixels come out NaN.
+ * Numerics: within max(1e-3, one fp16 ulp) of a scalar fp32 evaluation of the HLSL per channel (tests/test_gpu_parity.py).
+ * Where the reference shades anything, this returns UR_EUNSUPPORTED for: a ViewInverse whose upper 3x3 is not a rotation
+ * to 1e-3 (the kernels carry vectors between view and world space as rigid transforms; a camera built by LookToLH always
+ * is), a shadow map smaller than 3x3 texels with ShadowStrength > 0, and a band of 2^29 pixels or more in one call.
+ * Everything else is shaded by one of two kernels (a streaming one for the common shapes, a per-tile one for the rest: a
+ * width that is not a multiple of 16, a perspective light, a LUT that is not 128x32, ...) with the same values. */
 int ur_deferred_lighting(ur_ctx* ctx, const ur_scene_constants* scene, const ur_half4* gbuf_a,
                          const ur_half4* gbuf_b, const uint32_t* gbuf_c, const ur_lighting_tables* tables,
                          ur_half4* hdr_inout, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows);
@@ -234,7 +240,9 @@ typedef struct ur_tonemap_constants {
 
 /* Tonemap.hlsl:57-79 over a band of w x rows pixels: hdr (RGBA16F) * Exposure [* 2^exposure_ev[0] when auto exposure is
  * on; exposure_ev = device pointer to the LogAverageLuminance texel, nullable], Khronos PBR-neutral curve, saturate,
- * pow(1/max(Gamma,1e-3)), written as R8G8B8A8_UNORM (R in the low byte, A = 255). 12 B/pixel. */
+ * pow(1/max(Gamma,1e-3)), written as R8G8B8A8_UNORM (R in the low byte, A = 255). 12 B/pixel.
+ * Numerics: each byte within 1 LSB of a scalar evaluation with libm's powf (the kernel raises through exp2/log2 and divides
+ * through v_rcp; the reference's own pow is the D3D driver's); every launch shape gives the same bits for the same pixel. */
 int ur_tonemap(ur_ctx* ctx, const ur_tonemap_constants* constants, const ur_half4* hdr, const float* exposure_ev, uint32_t* out_rgba8,
                uint32_t w, uint32_t rows);
 
