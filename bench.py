@@ -425,12 +425,13 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 math, fp16 G-buffer/HDR I/O",
+        "dtype": "f32",  # the arithmetic type of the path (G-buffer and HDR targets are fp16 / unorm8 in memory: config.storage)
         "data": "synthetic",
         "config": {
             "workload": f"Sponza {W}x{H} full pipeline: cull(25) + BuildHZB({lay.count} mips) + DeferredLighting+Sky fused"
                         + (" + Tonemap" if args.gather_ldr else "")
                         + (f", {N} row bands + RCCL all-gather of " + ("tonemapped RGBA8" if args.gather_ldr else "RGBA16F HDR") + (" (overlapped with the next frames)" if not args.sync_gather else "") if N > 1 else ""),
+            "storage": "G-buffer A/B and HDR RGBA16F, G-buffer C RGBA8 sRGB, depth / shadow map / HZB fp32",
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
