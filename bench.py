@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--gather-ldr", action="store_true",
                     help="add the Tonemap pass behind Lighting+Sky (Tonemap.hlsl) and, with N > 1, all-gather the tonemapped RGBA8 bands "
                          "(4 B/pixel over xGMI) instead of the RGBA16F ones (8 B/pixel)")
+    ap.add_argument("--gather", choices=["ring", "direct"], default="ring",
+                    help="N > 1: ring = one all_gather_into_tensor per frame (RCCL's ring / tree); direct = N - 1 grouped send/receive pairs "
+                         "per rank, one per xGMI link (unclerenderer_amd/dist.py, ur_allgather_rows_bytes_ex)")
     ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="host pacing: the host waits (once every 64 frames) until the GPU is within this many frames of it (the reference "
@@ -224,13 +227,13 @@ def main():
         s["res"] = Frame.resources(W, H, row0, band, s["A"], s["B"], s["C"], s["depth_band"], s["hdr_band"], s["depth_full"], hzb, lay, tables,
                                    d_bounds, d_args, i1 - i0, i0, d_vis, d_cnt, None, s.get("ldr_band"))
 
-    # roofline leg: the Lighting pass of every timed frame is bracketed by a HIP event pair on the stream it is launched on
-    timed_flags = flags if args.no_light_events else (flags | urlib.UR_FRAME_TIME_LIGHTING)
-
-    # One timed frame in 32 carries the Lighting event pair (two records: ~10 us of queue time); a short run (the driver's
-    # --steps 20) takes two samples. What a record costs is measured OUTSIDE the timed region (calibration frames below).
-    # (the two records of a sampled frame cost ~10 us of queue time: one frame in 32 keeps that under 0.4 % of the frame rate)
-    light_every = 32 if args.steps >= 256 else (8 if args.steps >= 64 else max(2, (args.steps + 1) // 2))
+    # roofline leg: the Lighting launch of the sampled timed frames carries a HIP event pair ON ITS OWN DISPATCH
+    # (ur_time_next_lighting -> hipExtLaunchKernel on the stream the kernel is launched on): the pair's distance is the
+    # dispatch's begin -> end interval as the command processor stamps it — the quantity rocprofv3's kernel trace reports
+    # (profiles/: same command) — and no event-record packet sits in the queue around the kernel. Every frame of a short
+    # run (the driver's --steps 20 gives 20 samples), one in four of a long one.
+    timed_flags = flags if args.no_light_events else (flags | urlib.UR_FRAME_TIME_LIGHTING_KERNEL)
+    light_every = 1 if args.steps <= 64 else 4
 
     from collections import deque
     pace_marks = deque()
@@ -265,9 +268,9 @@ def main():
             # RCCL all-gather of the bands on the communication stream, behind this frame's passes; the next frames (other
             # buffer sets of the ring) are shaded while it runs — frames in flight, as the reference keeps three
             if args.gather_ldr:
-                s["gather"] = urdist.allgather_rows(s["ldr_full"], s["ldr_band"], async_op=not args.sync_gather)
+                s["gather"] = urdist.allgather_rows(s["ldr_full"], s["ldr_band"], async_op=not args.sync_gather, mode=args.gather)
             else:
-                s["gather"] = urdist.allgather_hdr(s["hdr_full"], s["hdr_band"], async_op=not args.sync_gather)
+                s["gather"] = urdist.allgather_hdr(s["hdr_full"], s["hdr_band"], async_op=not args.sync_gather, mode=args.gather)
 
     def fence():
         for s in sets:
@@ -364,7 +367,19 @@ def main():
         dt = float(t.item())
 
     light_ms, _ = (a.astype(np.float64) for a in frame.lighting_times_and_record_cost_ms())  # inside the timed region
-    # calibration (untimed): the same frames with a third event recorded right behind each pair
+    # The same frames once more with Python's collector left on (a host that drives frames from Python without freezing it):
+    # reported beside `value`, never instead of it
+    gc_on = None
+    if not args.python_gc and N == 1:
+        gc.unfreeze()  # (the timed region above ran with the set-up heap frozen and the collector off)
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k, False)
+        fence()
+        dt_gc = time.perf_counter() - t1
+        gc_on = {"value": W * H * args.steps / dt_gc / 1e6, "ms_per_step": dt_gc / args.steps * 1e3}
+    # secondary (untimed frames): the Lighting pass between an ordinary event pair (hipEventRecord in front and behind), with a
+    # third event recorded right behind each pair: what round 2 reported (bracket, and bracket minus one record's cost)
     for k in range(32):
         s_ = sets[k % ring]
         if s_.get("gather") is not None:
@@ -372,10 +387,12 @@ def main():
             s_["gather"] = None
         frame.render(s_["res"], cull_consts, fc.scene, fc.sky, flags | urlib.UR_FRAME_TIME_LIGHTING_RECORD_COST)
     fence()
-    cal_ms, record_ms = (a.astype(np.float64) for a in frame.lighting_times_and_record_cost_ms())
+    bracket_ms, record_ms = (a.astype(np.float64) for a in frame.lighting_times_and_record_cost_ms())
     record_ms = record_ms[record_ms >= 0]
     if record_ms.size == 0:
         record_ms = np.zeros(1)
+    if bracket_ms.size == 0:
+        bracket_ms = np.zeros(1)
     # the same kernel in a loop of its own (no visibility passes around it): ONE event pair around the whole batch, so that
     # no event record sits between two launches (the figure includes the ~2 us boundary between back-to-back launches)
     n_alone = min(max(args.steps, 50), 300)
@@ -391,7 +408,7 @@ def main():
     torch.cuda.synchronize()
     alone_ms = np.array([e0.elapsed_time(e1) / n_alone], dtype=np.float64)
     if light_ms.size == 0:
-        light_ms, record_ms = alone_ms, np.zeros(1)
+        light_ms = alone_ms
     n_sky = int((g.depth == 0).sum())
     n_geo = g.depth.size - n_sky
     # algorithmic bytes of one fused launch on this rank: geometry pixels read A 8 + B 8 + C 4 + depth 4 + HDR 8 and write
@@ -402,12 +419,12 @@ def main():
     rides = args.hzb_launch == "ride" and not args.async_compute
     hzb_bytes = 4 * (W * H + lay.mip_texels())
     light_bytes = light_only_bytes + (hzb_bytes if rides else 0)
-    # An event pair brackets [record, launch, record]: the record in front of the launch sits inside the bracket. Its cost is
-    # measured in the same frames by a third event recorded right behind the pair (nothing in between) and taken out; the
-    # result is what rocprofv3's kernel trace reports for the dispatch (profiles/: same command). Raw values are reported too.
-    bracket_avg_s = float(light_ms.mean()) * 1e-3
+    # ... counting the depth buffer ONCE: the riding chain's read of it is the launch's second (the tile DMA has fetched the
+    # same rows for the sky test), so the launch's compulsory bytes are smaller by one depth buffer
+    light_bytes_dedup = light_bytes - (4 * W * band if (rides and N == 1) else 0)
+    light_avg_s = float(light_ms.mean()) * 1e-3        # dispatch begin -> end, averaged over the samples of the timed region
+    bracket_avg_s = float(bracket_ms.mean()) * 1e-3    # secondary: [record, launch, record] of the untimed frames behind it
     record_avg_s = float(record_ms.mean()) * 1e-3
-    light_avg_s = bracket_avg_s - record_avg_s
     achieved = light_bytes / light_avg_s / 1e9
 
     result = {
@@ -430,7 +447,7 @@ def main():
         "config": {
             "workload": f"Sponza {W}x{H} full pipeline: cull(25) + BuildHZB({lay.count} mips) + DeferredLighting+Sky fused"
                         + (" + Tonemap" if args.gather_ldr else "")
-                        + (f", {N} row bands + RCCL all-gather of " + ("tonemapped RGBA8" if args.gather_ldr else "RGBA16F HDR") + (" (overlapped with the next frames)" if not args.sync_gather else "") if N > 1 else ""),
+                        + (f", {N} row bands + RCCL {'all-gather' if args.gather == 'ring' else 'direct send/recv gather'} of " + ("tonemapped RGBA8" if args.gather_ldr else "RGBA16F HDR") + (" (overlapped with the next frames)" if not args.sync_gather else "") if N > 1 else ""),
             "storage": "G-buffer A/B and HDR RGBA16F, G-buffer C RGBA8 sRGB, depth / shadow map / HZB fp32",
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
@@ -440,9 +457,13 @@ def main():
         "roofline": {
             "kernel": "lighting_stream_kernel<FUSED>" + (" carrying the Build HZB chain (wave pieces + tail workgroup)" if rides else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": (float(light_ms.min()) - float(record_ms.mean())) * 1e3,
+            "timing": "HIP event pair carried on the kernel dispatch (hipExtLaunchKernel), timed region",
+            "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float(light_ms.min()) * 1e3,
+            "median_launch_us": float(np.median(light_ms)) * 1e3,
+            "bytes_per_launch_dedup": light_bytes_dedup, "frac_dedup": light_bytes_dedup / light_avg_s / 1e9 / HBM_PEAK_GBS,
             "event_bracket_us": bracket_avg_s * 1e6, "event_record_us": record_avg_s * 1e6,
-            "frac_uncorrected": light_bytes / bracket_avg_s / 1e9 / HBM_PEAK_GBS,
+            "frac_event_bracket": light_bytes / bracket_avg_s / 1e9 / HBM_PEAK_GBS if bracket_avg_s > 0 else None,
+            "frac_event_bracket_minus_record": light_bytes / (bracket_avg_s - record_avg_s) / 1e9 / HBM_PEAK_GBS if bracket_avg_s > record_avg_s else None,
             "lighting_bytes": light_only_bytes, "hzb_bytes_in_launch": hzb_bytes if rides else 0,
             "frac_lighting_bytes_only": light_only_bytes / light_avg_s / 1e9 / HBM_PEAK_GBS,
             "shade_only_mpixels_per_s": g.depth.size * N / light_avg_s / 1e6,
@@ -467,6 +488,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline(fc, g, shadow, env, lut, bounds, lay, W, H)
     if timeline is not None:
         result["timeline"] = timeline
+    if gc_on is not None:
+        result["with_python_gc_on"] = gc_on
     if rank == 0:
         result["setup_seconds"] = round(gen_s, 1)
         print(json.dumps(result))

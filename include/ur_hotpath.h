@@ -34,6 +34,8 @@ extern "C" {
 #define UR_ENOMEM (-3)       /* workspace allocation failed */
 #define UR_ENODEVICE (-4)    /* no usable gfx950 device */
 #define UR_EUNSUPPORTED (-5) /* valid request outside what the kernels implement */
+#define UR_ETIMEOUT (-6)     /* a riding Build HZB chain's tail gave up waiting for its producers inside a Lighting launch: the HZB's
+                                levels from the tail's first one on are stale (ur_flush / ur_build_hzb / ur_cull_indirect_args* report it) */
 
 #define UR_MAX_HZB_MIPS 16u
 #define UR_CULL_CONSTANT_DWORDS 46u
@@ -144,12 +146,24 @@ int ur_reserve(ur_ctx* ctx, uint32_t max_instances);
  * out first); the depth buffer must stay unchanged until then as well. */
 int ur_defer_hzb_tail(ur_ctx* ctx, int mode /* 0 off, 1 tail, 2 whole chain */);
 int ur_flush(ur_ctx* ctx);
+/* Debug: sets the context's time-out flag as the riding tail workgroup does when it gives up waiting (a bounded wait inside
+ * the Lighting launch, see UR_ETIMEOUT): the next ur_flush / ur_build_hzb / ur_cull_indirect_args* / ur_frame_render on the
+ * context returns UR_ETIMEOUT once. For tests of the host's error path. */
+int ur_debug_set_hzb_timeout(ur_ctx* ctx);
 /* Debug: a GPU-side timeline of the context's launches. device_pairs: capacity_pairs x 2 uint64 in device memory, every pair
  * initialised by the caller to {~0, 0}. From then on each cull launch and each streaming Lighting launch on the context takes
  * the next pair (until the array is full) and folds the constant 100 MHz clock (s_memrealtime) into it: [0] = first workgroup's entry, [1] = last
  * workgroup's exit. Gaps between consecutive launches are then read off without a profiler (bench.py --timeline). NULL
  * switches it off (the default: the kernels then execute one scalar branch for it). */
 int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t capacity_pairs);
+/* Timing: the NEXT ur_deferred_lighting / ur_deferred_lighting_sky launch on the context carries this pair of HIP events
+ * (hipEvent_t, created by the caller with timing enabled) on the kernel dispatch itself (hipExtLaunchKernel): after the
+ * stream has been synchronised hipEventElapsedTime(start, stop) is the dispatch's own begin -> end interval as the command
+ * processor stamps it, the figure rocprofv3's kernel trace reports for it, with no event-record packet in the queue around
+ * the kernel. One-shot: the pair is consumed by that launch (by the main kernel of it: a held-back HZB tail that has to go
+ * out in front is not timed). The reference's counterpart is the timestamp-query pair FRenderGraph puts around a pass
+ * (Source/Render/RenderGraph.cpp:402-406,475-478). NULL, NULL clears a pair that was not consumed. */
+int ur_time_next_lighting(ur_ctx* ctx, void* start_event, void* stop_event);
 const char* ur_last_error(void);
 const char* ur_version(void);
 
@@ -264,6 +278,15 @@ int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, u
  * 4 B/pixel over xGMI instead of 8; SURVEY.md §8f-1, Shaders/Tonemap.hlsl:57-79). */
 int ur_allgather_rows_bytes(ur_ctx* ctx, void* comm, void* image, uint32_t row_bytes, uint32_t h, uint32_t n_ranks,
                             uint32_t rank);
+/* The same with the form of the exchange chosen by the caller. UR_GATHER_RING: one ncclAllGather (RCCL picks ring or tree).
+ * UR_GATHER_DIRECT: ncclGroupStart, N - 1 ncclSend / ncclRecv pairs (this rank's band to every peer, every peer's band
+ * into its rows), ncclGroupEnd — every transfer crosses exactly the one xGMI link its two GPUs share and all of a rank's
+ * seven are in flight together, which is the floor SURVEY.md H1 prices (band_bytes / 153 GB/s), with no ring hops.
+ * Same result bytes. */
+#define UR_GATHER_RING 0
+#define UR_GATHER_DIRECT 1
+int ur_allgather_rows_bytes_ex(ur_ctx* ctx, void* comm, void* image, uint32_t row_bytes, uint32_t h, uint32_t n_ranks,
+                               uint32_t rank, int mode);
 
 #ifdef __cplusplus
 }

@@ -121,20 +121,45 @@ def cpu_frustum(planes24: np.ndarray, bounds: np.ndarray) -> np.ndarray:
     return out
 
 
+class FragileMask(np.ndarray):
+    """The fragile-pixel mask of deferred_lighting (1 where a shadow compare is within 1e-5 of flipping) carrying, when any
+    pixel is fragile, the two images that bracket every admissible outcome of those pixels: `lo` (every tie fails) and
+    `hi` (every tie passes). tests/util.py:hdr_mismatch holds fragile pixels to that interval."""
+    lo = None
+    hi = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None and getattr(obj, "shape", None) == self.shape:
+            self.lo, self.hi = getattr(obj, "lo", None), getattr(obj, "hi", None)
+
+
 def deferred_lighting(scene, A, B, Cc, shadow, env_cube, env_base, env_mips, lut, hdr, w, h, row0=0, rows=None,
-                      want_fragile=False):
-    """scene: a ctypes struct laid out as ur_scene_constants. Arrays are band-local. Returns hdr_out[, fragile]."""
+                      want_fragile=False, tie_mode=0):
+    """scene: a ctypes struct laid out as ur_scene_constants. Arrays are band-local. Returns hdr_out[, fragile].
+    tie_mode: 0 the reference's compare; +1 / -1 every shadow compare within 1e-5 of flipping passes / fails."""
     rows = A.shape[0] if rows is None else rows
+    if want_fragile and tie_mode == 0:
+        out, frag = deferred_lighting(scene, A, B, Cc, shadow, env_cube, env_base, env_mips, lut, hdr, w, h, row0, rows, True, tie_mode=None)
+        frag = frag.view(FragileMask)
+        if frag.any():
+            frag.lo = deferred_lighting(scene, A, B, Cc, shadow, env_cube, env_base, env_mips, lut, hdr, w, h, row0, rows, False, tie_mode=-1)
+            frag.hi = deferred_lighting(scene, A, B, Cc, shadow, env_cube, env_base, env_mips, lut, hdr, w, h, row0, rows, False, tie_mode=+1)
+        return out, frag
+    tie_mode = tie_mode or 0
     A = np.ascontiguousarray(A, np.uint16); B = np.ascontiguousarray(B, np.uint16); Cc = np.ascontiguousarray(Cc, np.uint32)
     out = np.ascontiguousarray(hdr, np.uint16).copy()
     lut = np.ascontiguousarray(lut, np.uint16)
     env_cube = np.ascontiguousarray(env_cube, np.uint16)
     sh = np.ascontiguousarray(shadow, np.float32) if shadow is not None else None
     frag = np.zeros((rows, w), np.uint8) if want_fragile else None
-    load().uro_deferred_lighting(C.byref(scene), _p(A), _p(B), _p(Cc), _p(sh) if sh is not None else None, _p(env_cube),
-                                 C.c_uint32(env_base), C.c_uint32(env_mips), _p(lut), C.c_uint32(lut.shape[1]), C.c_uint32(lut.shape[0]),
-                                 _p(out), C.c_uint32(w), C.c_uint32(h), C.c_uint32(row0), C.c_uint32(rows),
-                                 _p(frag) if frag is not None else None)
+    load().uro_set_shadow_tie_mode(C.c_int(tie_mode))
+    try:
+        load().uro_deferred_lighting(C.byref(scene), _p(A), _p(B), _p(Cc), _p(sh) if sh is not None else None, _p(env_cube),
+                                     C.c_uint32(env_base), C.c_uint32(env_mips), _p(lut), C.c_uint32(lut.shape[1]), C.c_uint32(lut.shape[0]),
+                                     _p(out), C.c_uint32(w), C.c_uint32(h), C.c_uint32(row0), C.c_uint32(rows),
+                                     _p(frag) if frag is not None else None)
+    finally:
+        load().uro_set_shadow_tie_mode(C.c_int(0))
     return (out, frag) if want_fragile else out
 
 

@@ -24,6 +24,7 @@
 #include "../include/ur_hotpath.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -455,17 +456,27 @@ float2 SampleLutBilinear(const uint16_t* lut, uint32_t W, uint32_t H, float u, f
     return {lerp(lerp(t00.x, t10.x, fx), lerp(t01.x, t11.x, fx), fy), lerp(lerp(t00.y, t10.y, fx), lerp(t01.y, t11.y, fx), fy)};
 }
 
+// How a comparison within 1e-5 of flipping is resolved: 0 = as computed (the reference's answer), +1 = every such tie
+// passes, -1 = every such tie fails. The two forced modes bracket what ANY correctly rounded evaluation of the shadow
+// coordinate can return for such a pixel (the shaded colour is monotone in each tap): the parity tests hold those pixels
+// to that interval instead of skipping them (uro_set_shadow_tie_mode; tests/util.py:hdr_mismatch).
+std::atomic<int> g_tie_mode{0};
+
 // Texture2D.SampleCmpLevelZero, COMPARISON_MIN_MAG_LINEAR_MIP_POINT, BORDER opaque white, LESS_EQUAL
 // (DeferredRenderer.cpp:1723-1728). `tie` is set when a comparison is within 1e-5 of flipping.
 float SampleCmpLevelZero(const float* map, uint32_t W, uint32_t H, float u, float v, float cmp, bool* tie)
 {
+    const int tie_mode = g_tie_mode.load(std::memory_order_relaxed);
     const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     const float x0 = std::floor(x), y0 = std::floor(y);
     const float fx = x - x0, fy = y - y0;
     const int i0 = (int)x0, j0 = (int)y0;
     auto tap = [&](int i, int j) {
         const float t = (i < 0 || j < 0 || i >= (int)W || j >= (int)H) ? 1.0f : map[(size_t)j * W + i];
-        if (std::fabs(cmp - t) <= 1e-5f) *tie = true;
+        if (std::fabs(cmp - t) <= 1e-5f) {
+            *tie = true;
+            if (tie_mode != 0) return tie_mode > 0 ? 1.0f : 0.0f;
+        }
         return cmp <= t ? 1.0f : 0.0f;
     };
     const float r00 = tap(i0, j0), r10 = tap(i0 + 1, j0), r01 = tap(i0, j0 + 1), r11 = tap(i0 + 1, j0 + 1);
@@ -763,6 +774,8 @@ void uro_cpu_frustum(const float* planes24, const ur_float4* bounds, uint32_t n,
         out[i] = IsAabbInCameraFrustum(P, float3{mn.x, mn.y, mn.z}, float3{mx.x, mx.y, mx.z}) ? 1 : 0;
     }
 }
+
+void uro_set_shadow_tie_mode(int mode) { g_tie_mode.store(mode > 0 ? 1 : (mode < 0 ? -1 : 0)); }
 
 // Lighting pass over band rows [row0,row0+rows) (band-local buffers), additive ONE/ONE blend.
 // env_cube: DDS order, unbordered. fragile (nullable): per band pixel, 1 when a shadow compare is within

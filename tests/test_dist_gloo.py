@@ -40,12 +40,24 @@ def _worker(rank, world, port, w, h, n_inst, out_dir):
         assert work is not None
         work.wait()
         assert torch.equal(hdr_async, hdr_full)
+        # the direct form (N - 1 isend / irecv pairs per rank in one batch; on RCCL a grouped ncclSend / ncclRecv): same bytes,
+        # blocking and as a handle
+        hdr_direct = torch.zeros((h, w, 4), dtype=torch.int16)
+        assert urdist.allgather_hdr(hdr_direct, torch.from_numpy(band.view(np.int16)), mode="direct") is None
+        assert torch.equal(hdr_direct, hdr_full)
+        hdr_direct2 = torch.zeros((h, w, 4), dtype=torch.int16)
+        work = urdist.allgather_hdr(hdr_direct2, torch.from_numpy(band.view(np.int16)), async_op=True, mode="direct")
+        work.wait()
+        assert torch.equal(hdr_direct2, hdr_full)
         # Tonemap ahead of the gather (bench.py --gather-ldr): the band is tonemapped where it was shaded and the 4-byte
         # pixels travel instead of the 8-byte ones
         ldr_band = o.tonemap(band, exposure=0.9, gamma=2.2)
         ldr_full = torch.zeros((h, w), dtype=torch.int32)
         work = urdist.allgather_rows(ldr_full, torch.from_numpy(ldr_band.view(np.int32)), async_op=True)
         work.wait()
+        ldr_direct = torch.zeros((h, w), dtype=torch.int32)
+        urdist.allgather_rows(ldr_direct, torch.from_numpy(ldr_band.view(np.int32)), mode="direct")
+        assert torch.equal(ldr_direct, ldr_full)
         assert ldr_full.element_size() * ldr_full[0].numel() * 2 == hdr_full.element_size() * hdr_full[0].numel()  # half the bytes per row
         # cull: instance ranges + replicated HZB
         depth_full = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 17).depth

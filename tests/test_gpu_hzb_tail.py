@@ -354,3 +354,83 @@ def test_whole_chain_rides_with_a_short_band(hotpath, rows, row0):
             assert torch.equal(hzb, ref_hzb) and torch.equal(hdr, ref_hdr), it
     finally:
         hotpath.defer_hzb_tail(0)
+
+
+def test_riding_tail_timeout_is_reported_once_by_the_next_entry_point(hotpath):
+    """The riding tail workgroup's wait for its producers is bounded; giving up sets a host-visible flag (UR_ETIMEOUT,
+    include/ur_hotpath.h). The host side of that path, driven by the debug entry point that sets the flag as the kernel
+    does: each entry point that depends on the HZB reports it exactly once, does nothing else in that call, and the context
+    is usable afterwards (the same calls then succeed and give the reference bits)."""
+    import torch
+    from unclerenderer_amd import hostmath, lib, synth
+    from unclerenderer_amd.hotpath import to_device
+    w, h = 1024, 512
+    fc, g, tables, lay, dev = _setup(hotpath, w, h)
+    ref_hzb, ref_hdr = _reference(hotpath, fc, g, tables, lay, dev, w, h)
+    L = lib.load()
+    # ur_flush
+    assert L.ur_debug_set_hzb_timeout(hotpath.ctx) == lib.UR_OK
+    assert L.ur_flush(hotpath.ctx) == lib.UR_ETIMEOUT
+    assert b"gave up waiting" in L.ur_last_error()
+    assert L.ur_flush(hotpath.ctx) == lib.UR_OK, "reported once"
+    # ur_build_hzb: refuses (nothing is launched), then builds
+    hzb = torch.full((lay.total,), -1.0, device="cuda")
+    assert L.ur_debug_set_hzb_timeout(hotpath.ctx) == lib.UR_OK
+    with pytest.raises(lib.UrError) as e:
+        hotpath.build_hzb(dev["D"], hzb, lay)
+    assert e.value.code == lib.UR_ETIMEOUT
+    torch.cuda.synchronize()
+    assert float(hzb.max()) == -1.0, "the refused call launched nothing"
+    hotpath.build_hzb(dev["D"], hzb, lay)
+    torch.cuda.synchronize()
+    assert torch.equal(hzb, ref_hzb)
+    # ur_cull_indirect_args: a cull against a stale HZB is refused, not run
+    n = 500
+    bounds = to_device(synth.instances_random(n, 5, center=fc.camera_position, box=60.0))
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, n, True, lay.count, lay.width, lay.height, False)
+    args0 = synth.indirect_args_initial(n)
+    d_args = to_device(args0)
+    assert L.ur_debug_set_hzb_timeout(hotpath.ctx) == lib.UR_OK
+    with pytest.raises(lib.UrError) as e:
+        hotpath.cull_indirect_args(consts, bounds, hzb, lay, d_args)
+    assert e.value.code == lib.UR_ETIMEOUT
+    torch.cuda.synchronize()
+    assert np.array_equal(d_args.cpu().numpy().view(np.uint32).reshape(args0.shape), args0), "the refused cull wrote nothing"
+    hotpath.cull_indirect_args(consts, bounds, hzb, lay, d_args)
+    torch.cuda.synchronize()
+    # the whole chain riding a Lighting launch still works on this context (the arrival counter was reset by the report)
+    hzb2 = torch.full((lay.total,), -1.0, device="cuda")
+    hdr = to_device(g.hdr)
+    hotpath.defer_hzb_tail(2)
+    try:
+        hotpath.build_hzb(dev["D"], hzb2, lay)
+        hotpath.deferred_lighting_sky(fc.scene, fc.sky, dev["A"], dev["B"], dev["C"], dev["D"], tables, hdr, w, h)
+        torch.cuda.synchronize()
+    finally:
+        hotpath.defer_hzb_tail(False)
+    assert torch.equal(hzb2, ref_hzb) and torch.equal(hdr, ref_hdr)
+    assert L.ur_flush(hotpath.ctx) == lib.UR_OK, "a launch that completed its wait leaves no flag behind"
+
+
+def test_frame_render_reports_a_riding_tail_timeout(hotpath):
+    import torch
+    from unclerenderer_amd import hostmath, lib
+    from unclerenderer_amd.hotpath import Frame, to_device
+    w, h = 512, 256
+    fc, g, tables, lay, dev = _setup(hotpath, w, h)
+    hzb = torch.zeros(lay.total, device="cuda")
+    hdr = to_device(g.hdr)
+    frame = Frame(hotpath)
+    res = Frame.resources(w, h, 0, h, dev["A"], dev["B"], dev["C"], dev["D"], hdr, dev["D"], hzb, lay, tables)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, 0, True, lay.count, lay.width, lay.height, False)
+    flags = lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY | lib.UR_FRAME_HZB_WITH_LIGHTING
+    frame.render(res, consts, fc.scene, fc.sky, flags)
+    torch.cuda.synchronize()
+    L = lib.load()
+    assert L.ur_debug_set_hzb_timeout(hotpath.ctx) == lib.UR_OK
+    with pytest.raises(lib.UrError) as e:
+        frame.render(res, consts, fc.scene, fc.sky, flags)
+    assert e.value.code == lib.UR_ETIMEOUT
+    frame.render(res, consts, fc.scene, fc.sky, flags)  # reported once
+    torch.cuda.synchronize()
+    frame.close()

@@ -51,6 +51,15 @@ def test_allgather_rows_on_a_one_rank_communicator(hotpath):
         assert L.ur_allgather_rows_bytes(hotpath.ctx, comm, C.c_void_p(ldr.data_ptr()), w * 4, h, 1, 0) == lib.UR_OK, L.ur_last_error()
         torch.cuda.synchronize()
         assert torch.equal(ldr, want8)
+        # the direct form (grouped ncclSend / ncclRecv pairs, UR_GATHER_DIRECT): with one rank the group is empty, the symbols
+        # are resolved and the group calls are made on the same communicator; the ring form through the _ex entry point
+        UR_GATHER_RING, UR_GATHER_DIRECT = 0, 1
+        assert L.ur_allgather_rows_bytes_ex(hotpath.ctx, comm, C.c_void_p(ldr.data_ptr()), w * 4, h, 1, 0, UR_GATHER_DIRECT) == lib.UR_OK, L.ur_last_error()
+        assert L.ur_allgather_rows_bytes_ex(hotpath.ctx, comm, C.c_void_p(ldr.data_ptr()), w * 4, h, 1, 0, UR_GATHER_RING) == lib.UR_OK, L.ur_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(ldr, want8)
+        assert L.ur_allgather_rows_bytes_ex(hotpath.ctx, comm, C.c_void_p(ldr.data_ptr()), w * 4, h, 1, 0, 2) == lib.UR_EINVAL  # no such mode
+        assert L.ur_allgather_rows_bytes_ex(hotpath.ctx, comm, C.c_void_p(ldr.data_ptr()), w * 4, 65, 8, 0, UR_GATHER_DIRECT) == lib.UR_EINVAL
         # argument validation: every bad call is refused before RCCL is reached
         p = C.c_void_p(hdr.data_ptr())
         assert L.ur_allgather_rows(hotpath.ctx, None, p, w, h, 1, 0) == lib.UR_EINVAL          # no communicator

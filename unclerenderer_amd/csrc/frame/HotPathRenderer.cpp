@@ -199,6 +199,7 @@ struct ur_frame
     std::vector<FLightEvents> LightEvents; // ring: an event pair around the Lighting pass + one more right behind it (what a record costs)
     size_t LightHead = 0, LightCount = 0;
     bool bRecordAfter = false; // this frame's bracket gets the third event (UR_FRAME_TIME_LIGHTING_RECORD_COST)
+    bool bKernelEvents = false; // UR_FRAME_TIME_LIGHTING_KERNEL: the pair rides on the Lighting dispatch itself, nothing is recorded around it
     ur_frame(ur_ctx* Ctx, hipStream_t Stream, uint32 Frames, int Rank, int World) : Cmd(Ctx, Stream, Frames, Rank, World), Renderer(&Device) {}
 };
 
@@ -215,6 +216,17 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
             if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventCreate(&c) == hipSuccess) f->LightEvents.push_back({a, b, c, false});
         }
         if (f->LightEvents.empty()) return;
+        if (f->bKernelEvents) {
+            if (begin) {
+                f->LightHead = f->LightCount % f->LightEvents.size();
+                (void)ur_time_next_lighting(f->Cmd.GetContext(), f->LightEvents[f->LightHead].first, f->LightEvents[f->LightHead].second);
+            } else {
+                (void)ur_time_next_lighting(f->Cmd.GetContext(), nullptr, nullptr); // (a launch that failed validation consumed nothing)
+                f->LightEvents[f->LightHead].has_after = false;
+                ++f->LightCount;
+            }
+            return;
+        }
         if (begin) {
             f->LightHead = f->LightCount % f->LightEvents.size();
             (void)hipEventRecord(f->LightEvents[f->LightHead].first, s);
@@ -305,7 +317,8 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
         if (!f->AsyncCtx) return UR_EHIP;
         f->Cmd.SetAsyncCompute(f->AsyncCtx, f->AsyncStream);
     }
-    O.bTimeLighting = (flags & (UR_FRAME_TIME_LIGHTING | UR_FRAME_TIME_LIGHTING_RECORD_COST)) != 0;
+    O.bTimeLighting = (flags & (UR_FRAME_TIME_LIGHTING | UR_FRAME_TIME_LIGHTING_RECORD_COST | UR_FRAME_TIME_LIGHTING_KERNEL)) != 0;
+    f->bKernelEvents = (flags & UR_FRAME_TIME_LIGHTING_KERNEL) != 0;
     f->bRecordAfter = (flags & UR_FRAME_TIME_LIGHTING_RECORD_COST) != 0;
     O.bGpuTiming = (flags & UR_FRAME_GPU_TIMING) != 0;
     O.bGraphDump = (flags & UR_FRAME_GRAPH_DUMP) != 0;
@@ -319,7 +332,9 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     const int rc = f->Renderer.RenderFrame(f->Cmd, R, K, O);
     if (tail_with_lighting) {
         const int rc2 = ur_defer_hzb_tail(f->Cmd.GetContext(), 0); // launches the tail on its own if no Lighting launch took it
-        return rc != UR_OK ? rc : rc2;
+        // a riding tail that gave up waiting (a bounded wait inside an earlier Lighting launch) is reported here, once: UR_ETIMEOUT
+        const int rc3 = ur_flush(f->Cmd.GetContext());
+        return rc != UR_OK ? rc : (rc2 != UR_OK ? rc2 : rc3);
     }
     return rc;
 }

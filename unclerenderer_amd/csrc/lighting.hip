@@ -23,6 +23,8 @@
 #include "ur_device.h"
 #include "hzb_tail.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
@@ -761,7 +763,8 @@ struct HzbRide {
                              // meanwhile -, 16 when it is short - the chain must not outlast the shading (informative: the kernel
                              // instantiation, RIDE_ALL, carries the choice)
     uint32_t pad;
-    uint32_t* done;          // [0] arrivals (reset by the tail workgroup), [1] sticky flag: the tail gave up waiting
+    uint32_t* done;          // arrivals of this launch's lighting workgroups (reset by the tail workgroup once it has seen them all)
+    uint32_t* timed_out;     // host-visible (mapped, coherent) flag: the tail gave up waiting (ur_ctx::hzb_timed_out)
 };
 
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB, bool RIDE_ALL>
@@ -790,19 +793,26 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const KRide ride = (KRide)((const __attribute__((address_space(4))) char*)ka + sizeof(LightingParams) + sizeof(ur::HzbTail));
             if (ride->pieces != 0u) {
                 // The tail's parent level is written by the lighting workgroups of THIS launch: wait for all of them (a relaxed
-                // agent-scope poll by one lane, bounded: a lost arrival must not hang the chip), then acquire, then the barrier
-                // (MI355X_MICROARCH.md, inter-workgroup visibility: valid consumer form).
+                // agent-scope poll by one lane, then acquire, then the barrier: MI355X_MICROARCH.md, inter-workgroup visibility,
+                // valid consumer form). The wait cannot deadlock as launched: this is the launch's HIGHEST-indexed workgroup, the
+                // grid is one workgroup per CU, workgroups are dispatched in index order, so every producer is resident before
+                // this one starts. It is bounded all the same (~4 s of s_sleep): a lost arrival must not hang the chip. Giving up
+                // is NOT silent: the flag in host-visible memory makes the next ur_flush / ur_build_hzb / ur_cull_indirect_args* /
+                // ur_frame_render on the context return UR_ETIMEOUT (the levels below are then built from a stale parent), and
+                // the arrival counter is left as it is — stragglers may still add to it; the host resets it when it reports.
                 if (threadIdx.x == 0) {
                     uint32_t* done = ride->done;
                     const uint32_t want = p.hot.groups;
                     uint32_t spins = 0;
+                    bool gave_up = false;
                     while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                         __builtin_amdgcn_s_sleep(32);
-                        if (++spins > (1u << 22)) { __hip_atomic_store(done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (++spins > (1u << 22)) { gave_up = true; break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the next launch starts from zero
+                    if (gave_up) __hip_atomic_store(ride->timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the next launch starts from zero
                 }
                 __syncthreads();
             }
@@ -1426,6 +1436,19 @@ int env_int(const char* name, int dflt)
     return e ? std::atoi(e) : dflt;
 }
 
+// One Lighting launch. With a pair of events waiting on the context (ur_time_next_lighting) the dispatch itself carries
+// them (hipExtLaunchKernelGGL): their distance is the kernel's own begin -> end interval, no event record in the queue.
+template <class K, class... Args>
+void launch_timed(ur_ctx* ctx, K kern, dim3 grid, dim3 block, uint32_t lds, Args... args)
+{
+    if (ctx->time_start != nullptr && ctx->time_stop != nullptr) {
+        hipExtLaunchKernelGGL(kern, grid, block, lds, ctx->stream, ctx->time_start, ctx->time_stop, 0, args...);
+        ctx->time_start = ctx->time_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, args...);
+    }
+}
+
 // Per-tile kernel (one 64x4-pixel workgroup per tile): partial tiles, sky-only launches and configurations the streaming
 // kernel does not cover.
 template <int MODE, bool SHADOWS>
@@ -1435,8 +1458,8 @@ void launch_tiled(ur_ctx* ctx, const LightingParams& p)
     const uint32_t tilesX = (p.W + 4 * TW - 1) / (4 * TW), tilesY = (p.rows + (64 / TW) - 1) / (64 / TW);
     // register budget: waves/SIMD the kernel is compiled for (6 -> 80 VGPRs, the most that does not spill; 4 -> no cap)
     static const int waves = env_int("UR_LIGHTING_WAVES", 6);
-    if (waves >= 6) hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 6>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((lighting_kernel<MODE, SHADOWS, TW, 4>), dim3(tilesX, tilesY), dim3(256), 0, ctx->stream, p);
+    if (waves >= 6) launch_timed(ctx, lighting_kernel<MODE, SHADOWS, TW, 6>, dim3(tilesX, tilesY), dim3(256), 0u, p);
+    else launch_timed(ctx, lighting_kernel<MODE, SHADOWS, TW, 4>, dim3(tilesX, tilesY), dim3(256), 0u, p);
 }
 
 #ifdef UR_STAMPS
@@ -1480,6 +1503,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
             ride.grid_x = ctx->pending_wide_grid_x;
             ride.pieces = ctx->pending_wide_grid_x * ctx->pending_wide_grid_y;
             ride.done = ctx->hzb_done;
+            ride.timed_out = ctx->hzb_timed_out_dev;
             // walkers: the chain should be done within about a quarter of the shading (a piece is ~3 us of one wave's time, a
             // tile ~1.75 us): walkers >= 7 x pieces-per-workgroup / tiles-per-wave, rounded up to a power of two
             {
@@ -1510,7 +1534,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
         UR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0) attr_set[ride_all][dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(groups + (carry_tail ? 1u : 0u)), dim3(64 * WPB), lds, ctx->stream, p, tail, ride);
+    launch_timed(ctx, kern, dim3(groups + (carry_tail ? 1u : 0u)), dim3(64 * WPB), lds, p, tail, ride);
     return UR_OK;
 }
 

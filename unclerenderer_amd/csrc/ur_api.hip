@@ -26,6 +26,20 @@ void set_error(const char* fmt, ...)
 
 using ur::set_error;
 
+namespace ur {
+
+int check_hzb_timeout(ur_ctx* ctx, const char* who)
+{
+    if (!ctx || !ctx->hzb_timed_out || *ctx->hzb_timed_out == 0u) return UR_OK;
+    *ctx->hzb_timed_out = 0u;
+    (void)hipMemsetAsync(ctx->hzb_done, 0, 64, ctx->stream); // stragglers may have left any count behind
+    set_error("%s: the tail of a Build HZB chain that rode a Lighting launch gave up waiting for its producers: the HZB's small levels are stale — "
+              "build it again (reported once; the context is usable)", who);
+    return UR_ETIMEOUT;
+}
+
+} // namespace ur
+
 namespace {
 
 // ---- bordered cube staging (host) ------------------------------------------------------------------------------------
@@ -137,6 +151,19 @@ ur_ctx* ur_create(int device, void* stream)
         ur_destroy(ctx);
         return nullptr;
     }
+    {
+        void* host = nullptr;
+        void* devp = nullptr;
+        if (hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&devp, host, 0) != hipSuccess) {
+            if (host) (void)hipHostFree(host);
+            set_error("ur_create: host-visible time-out flag allocation failed");
+            ur_destroy(ctx);
+            return nullptr;
+        }
+        ctx->hzb_timed_out = static_cast<volatile uint32_t*>(host);
+        ctx->hzb_timed_out_dev = static_cast<uint32_t*>(devp);
+        *ctx->hzb_timed_out = 0u;
+    }
     if (ur_reserve(ctx, 1u << 20) != UR_OK) {
         ur_destroy(ctx);
         return nullptr;
@@ -152,6 +179,7 @@ void ur_destroy(ur_ctx* ctx)
     ctx->hzb_tail_pending = false;
     ctx->hzb_wide_pending = false;
     if (ctx->hzb_done) (void)hipFree(ctx->hzb_done);
+    if (ctx->hzb_timed_out) (void)hipHostFree(const_cast<uint32_t*>(ctx->hzb_timed_out));
     if (ctx->srgb_table) (void)hipFree(ctx->srgb_table);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
@@ -177,10 +205,27 @@ int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t ca
     return UR_OK;
 }
 
+int ur_time_next_lighting(ur_ctx* ctx, void* start_event, void* stop_event)
+{
+    if (!ctx || ((start_event == nullptr) != (stop_event == nullptr))) { set_error("ur_time_next_lighting: the events go together"); return UR_EINVAL; }
+    ctx->time_start = static_cast<hipEvent_t>(start_event);
+    ctx->time_stop = static_cast<hipEvent_t>(stop_event);
+    return UR_OK;
+}
+
 int ur_flush(ur_ctx* ctx)
 {
     if (!ctx) { set_error("ur_flush: null context"); return UR_EINVAL; }
+    const int trc = ur::check_hzb_timeout(ctx, "ur_flush");
+    if (trc != UR_OK) return trc;
     return ur::flush_hzb_tail(ctx);
+}
+
+int ur_debug_set_hzb_timeout(ur_ctx* ctx)
+{
+    if (!ctx || !ctx->hzb_timed_out) { set_error("ur_debug_set_hzb_timeout: null context"); return UR_EINVAL; }
+    *ctx->hzb_timed_out = 1u; // what the riding tail workgroup writes when it gives up
+    return UR_OK;
 }
 
 int ur_reserve(ur_ctx* ctx, uint32_t max_instances)
@@ -224,6 +269,8 @@ int ur_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h
 {
     if (!ctx || !depth || !hzb_base || src_w == 0 || src_h == 0) { set_error("ur_build_hzb: null/zero argument"); return UR_EINVAL; }
     if (!valid_hzb_chain(src_w, src_h, mips, mip_count)) { set_error("ur_build_hzb: mip chain does not match CreateHZBResources sizing"); return UR_EINVAL; }
+    const int trc = ur::check_hzb_timeout(ctx, "ur_build_hzb");
+    if (trc != UR_OK) return trc;
     return ur::launch_build_hzb(ctx, depth, src_w, src_h, hzb_base, mips, mip_count);
 }
 
@@ -241,6 +288,8 @@ int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_fl
         // the kernel indexes hzb + mips[level].offset with pitch mips[level].width for every level up to HZBMipCount - 1
         if (!valid_hzb_chain_below_mip0(mips, mipc)) { set_error("ur_cull_indirect_args: mips[1..%u] do not halve from mips[0] / overlap", mipc - 1); return UR_EINVAL; }
     }
+    const int trc = ur::check_hzb_timeout(ctx, "ur_cull_indirect_args");
+    if (trc != UR_OK) return trc;
     return ur::launch_cull(ctx, constants, bounds, hzb_base, mips, indirect_args, stats2, visible_idx, visible_count, index_base);
 }
 
@@ -326,29 +375,68 @@ int ur_deferred_lighting_sky(ur_ctx* ctx, const ur_scene_constants* scene, const
     return ur::launch_lighting(ctx, scene, sky, a, b, c, depth, tables, hdr, w, h, row0, rows, ur::UR_MODE_FUSED);
 }
 
-int ur_allgather_rows_bytes(ur_ctx* ctx, void* comm, void* image, uint32_t row_bytes, uint32_t h, uint32_t n_ranks, uint32_t rank)
+// RCCL is resolved at run time from whatever copy the host process already loaded globally (the communicator must come
+// from the same copy), falling back to the system's librccl: the library has no link-time dependency on RCCL.
+static void* rccl_symbol(const char* name)
+{
+    void* fn = dlsym(RTLD_DEFAULT, name);
+    if (!fn) {
+        static void* lib = nullptr;
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) fn = dlsym(lib, name);
+    }
+    return fn;
+}
+
+int ur_allgather_rows_bytes_ex(ur_ctx* ctx, void* comm, void* image, uint32_t row_bytes, uint32_t h, uint32_t n_ranks, uint32_t rank, int mode)
 {
     if (!ctx || !comm || !image || row_bytes == 0 || h == 0 || n_ranks == 0 || rank >= n_ranks || h % n_ranks != 0) {
         set_error("ur_allgather_rows: bad argument (row_bytes=%u h=%u ranks=%u rank=%u)", row_bytes, h, n_ranks, rank);
         return UR_EINVAL;
     }
-    // RCCL is resolved at run time from whatever copy the host process already loaded globally (the communicator must
-    // come from the same copy), falling back to the system's librccl: the library has no link-time dependency on RCCL.
-    static nccl_allgather_fn fn = nullptr;
-    if (!fn) {
-        fn = reinterpret_cast<nccl_allgather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
-        if (!fn) {
-            void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (lib) fn = reinterpret_cast<nccl_allgather_fn>(dlsym(lib, "ncclAllGather"));
-        }
-        if (!fn) { set_error("ur_allgather_rows: ncclAllGather not found"); return UR_EUNSUPPORTED; }
-    }
+    if (mode != UR_GATHER_RING && mode != UR_GATHER_DIRECT) { set_error("ur_allgather_rows: mode %d (0 ring, 1 direct)", mode); return UR_EINVAL; }
     const size_t band_bytes = (size_t)row_bytes * (h / n_ranks);
-    const char* send = reinterpret_cast<const char*>(image) + band_bytes * rank;
-    const int rc = fn(send, image, band_bytes, /*ncclInt8*/ 0, comm, ctx->stream);
-    if (rc != 0) { set_error("ncclAllGather failed (%d)", rc); return UR_EHIP; }
+    char* base = reinterpret_cast<char*>(image);
+    const char* send = base + band_bytes * rank;
+    if (mode == UR_GATHER_RING) {
+        static nccl_allgather_fn fn = nullptr;
+        if (!fn) fn = reinterpret_cast<nccl_allgather_fn>(rccl_symbol("ncclAllGather"));
+        if (!fn) { set_error("ur_allgather_rows: ncclAllGather not found"); return UR_EUNSUPPORTED; }
+        const int rc = fn(send, image, band_bytes, /*ncclInt8*/ 0, comm, ctx->stream);
+        if (rc != 0) { set_error("ncclAllGather failed (%d)", rc); return UR_EHIP; }
+        return UR_OK;
+    }
+    // Direct form: the band goes to every peer over the xGMI link the two GPUs share (an MI355X node is fully connected,
+    // 7 links per GPU), all N - 1 transfers of a rank in flight at once — one grouped call, no ring hops.
+    typedef int (*group_fn)(void);
+    typedef int (*send_fn)(const void*, size_t, int, int, void*, hipStream_t);
+    typedef int (*recv_fn)(void*, size_t, int, int, void*, hipStream_t);
+    static group_fn g_start = nullptr, g_end = nullptr;
+    static send_fn f_send = nullptr;
+    static recv_fn f_recv = nullptr;
+    if (!g_start) {
+        g_start = reinterpret_cast<group_fn>(rccl_symbol("ncclGroupStart"));
+        g_end = reinterpret_cast<group_fn>(rccl_symbol("ncclGroupEnd"));
+        f_send = reinterpret_cast<send_fn>(rccl_symbol("ncclSend"));
+        f_recv = reinterpret_cast<recv_fn>(rccl_symbol("ncclRecv"));
+    }
+    if (!g_start || !g_end || !f_send || !f_recv) { g_start = nullptr; set_error("ur_allgather_rows: ncclGroupStart/End, ncclSend, ncclRecv not found"); return UR_EUNSUPPORTED; }
+    int rc = g_start();
+    // peers in the order rank + 1, rank + 2, ...: at any moment every rank sends to a different peer
+    for (uint32_t k = 1; k < n_ranks && rc == 0; ++k) {
+        const uint32_t to = (rank + k) % n_ranks, from = (rank + n_ranks - k) % n_ranks;
+        rc = f_send(send, band_bytes, /*ncclInt8*/ 0, (int)to, comm, ctx->stream);
+        if (rc == 0) rc = f_recv(base + band_bytes * from, band_bytes, /*ncclInt8*/ 0, (int)from, comm, ctx->stream);
+    }
+    const int rc_end = g_end();
+    if (rc != 0 || rc_end != 0) { set_error("grouped ncclSend/ncclRecv failed (%d, %d)", rc, rc_end); return UR_EHIP; }
     return UR_OK;
+}
+
+int ur_allgather_rows_bytes(ur_ctx* ctx, void* comm, void* image, uint32_t row_bytes, uint32_t h, uint32_t n_ranks, uint32_t rank)
+{
+    return ur_allgather_rows_bytes_ex(ctx, comm, image, row_bytes, h, n_ranks, rank, UR_GATHER_RING);
 }
 
 int ur_allgather_rows(ur_ctx* ctx, void* comm, ur_half4* hdr_full, uint32_t w, uint32_t h, uint32_t n_ranks, uint32_t rank)

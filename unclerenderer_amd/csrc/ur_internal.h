@@ -46,7 +46,13 @@ struct ur_ctx {
     // streaming Lighting launch, in launch order (the caller initialises every pair to {~0, 0})
     unsigned long long* timeline = nullptr;
     uint32_t timeline_cap = 0, timeline_pos = 0;
-    uint32_t* hzb_done = nullptr; // device: [0] arrivals of the current launch (reset by the tail workgroup), [1] sticky time-out flag
+    uint32_t* hzb_done = nullptr; // device: arrivals of the current launch (reset by the tail workgroup)
+    // the riding tail's time-out flag: one word of mapped, coherent host memory the kernel writes (system scope) and the host
+    // reads without a synchronisation at its next entry point that depends on the HZB (check_hzb_timeout)
+    volatile uint32_t* hzb_timed_out = nullptr;
+    uint32_t* hzb_timed_out_dev = nullptr; // its device address
+    // ur_time_next_lighting: events the next Lighting launch carries on its dispatch (hipExtLaunchKernel); consumed by it
+    hipEvent_t time_start = nullptr, time_stop = nullptr;
 };
 
 namespace ur {
@@ -80,5 +86,8 @@ inline unsigned long long* next_timeline_pair(ur_ctx* ctx)
 }
 // launches a deferred HZB tail on its own if one is pending (ur_flush and every launch that reads or rewrites the HZB)
 int flush_hzb_tail(ur_ctx* ctx);
+// UR_ETIMEOUT (once) if a riding tail has given up waiting since the last check: clears the flag and resets the arrival
+// counter on the context's stream (the call that reports it does nothing else); UR_OK otherwise
+int check_hzb_timeout(ur_ctx* ctx, const char* who);
 
 } // namespace ur

@@ -41,27 +41,82 @@ def plan_instances(count: int, world: int, rank: int) -> tuple[int, int]:
     return rank * count // world, (rank + 1) * count // world
 
 
-def allgather_hdr(hdr_full: torch.Tensor, band: torch.Tensor, group=None, async_op: bool = False):
-    """hdr_full: (H, W, 4) 16-bit tensor on every rank; band: this rank's (H/N, W, 4) rows. One collective.
+class _Works:
+    """The requests of one direct gather behind the Work interface the ring form returns."""
+
+    def __init__(self, reqs, finish=None):
+        self._reqs, self._finish = reqs, finish
+
+    def wait(self):
+        for r in self._reqs:
+            r.wait()
+        if self._finish is not None:
+            self._finish()
+            self._finish = None
+        return True
+
+
+def _allgather_direct(full: torch.Tensor, band: torch.Tensor, group, async_op: bool):
+    """Every rank sends its band to every peer and receives every peer's band into that peer's rows: N - 1 send/receive
+    pairs per rank in ONE batch (on "nccl" = RCCL: ncclGroupStart ... ncclSend / ncclRecv ... ncclGroupEnd), each pair over the
+    one xGMI link its two GPUs share, all in flight together (SURVEY.md H1's direct-link floor) instead of RCCL's ring or
+    tree all-gather. Same bytes in `full` afterwards."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    fb = full.view(torch.uint8).view(world, -1)
+    mine = band.contiguous().view(torch.uint8).view(-1)
+    if mine.data_ptr() != fb[rank].data_ptr():
+        fb[rank].copy_(mine)
+    # gloo moves host memory only: device tensors are staged through the host around the exchange (the CPU tests, and the
+    # rehearsal of several ranks on one GPU); RCCL takes the device pointers as they are
+    staged = dist.get_backend(group) == "gloo" and full.is_cuda
+    src = mine.cpu() if staged else mine
+    dst = torch.empty((world, mine.numel()), dtype=torch.uint8) if staged else fb
+    ops = []
+    for k in range(1, world):  # peers in the order rank + 1, rank + 2, ...: at any moment every rank sends to a different peer
+        to, frm = (rank + k) % world, (rank - k) % world
+        ops.append(dist.P2POp(dist.isend, src, dist.get_global_rank(group, to) if group is not None else to, group))
+        ops.append(dist.P2POp(dist.irecv, dst[frm], dist.get_global_rank(group, frm) if group is not None else frm, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish():
+        if staged:
+            for frm in range(world):
+                if frm != rank:
+                    fb[frm].copy_(dst[frm])
+    w = _Works(reqs, finish)
+    if async_op:
+        return w
+    w.wait()
+    return None
+
+
+def allgather_hdr(hdr_full: torch.Tensor, band: torch.Tensor, group=None, async_op: bool = False, mode: str = "ring"):
+    """hdr_full: (H, W, 4) 16-bit tensor on every rank; band: this rank's (H/N, W, 4) rows. One collective
+    (mode "ring": all_gather_into_tensor, RCCL's choice of ring or tree) or one batch of N - 1 send/receive pairs per rank
+    (mode "direct": _allgather_direct).
 
     async_op=True returns the collective's Work handle (None when there is nothing to exchange): the gather runs on the
     backend's communication stream behind everything already queued on the current stream, and `work.wait()` makes the
     current stream wait for it — the caller overlaps it with the next frame's passes and waits before it touches
     `hdr_full` or `band` again."""
+    if mode not in ("ring", "direct"):
+        raise ValueError(f"gather mode {mode!r} (ring | direct)")
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         if band.data_ptr() != hdr_full.data_ptr():
             hdr_full.copy_(band.view_as(hdr_full))
         return None
+    if mode == "direct":
+        return _allgather_direct(hdr_full, band, group, async_op)
     # transported as bytes: neither RCCL nor gloo has a 16-bit integer type, and the payload is opaque fp16 bit patterns
     work = dist.all_gather_into_tensor(hdr_full.view(torch.uint8).view(-1), band.contiguous().view(torch.uint8).view(-1), group=group,
                                        async_op=async_op)
     return work if async_op else None
 
 
-def allgather_rows(full: torch.Tensor, band: torch.Tensor, group=None, async_op: bool = False):
+def allgather_rows(full: torch.Tensor, band: torch.Tensor, group=None, async_op: bool = False, mode: str = "ring"):
     """The same collective for any row-major image whose leading dimension is rows (the tonemapped R8G8B8A8 band,
     Tonemap.hlsl:57-79: 4 B/pixel instead of the HDR band's 8): `full` (H, ...) on every rank, `band` this rank's H/N rows."""
-    return allgather_hdr(full, band, group=group, async_op=async_op)
+    return allgather_hdr(full, band, group=group, async_op=async_op, mode=mode)
 
 
 def allgather_visible(visible_idx: torch.Tensor, visible_count: torch.Tensor, group=None) -> tuple[torch.Tensor, int]:

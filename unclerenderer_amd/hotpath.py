@@ -92,6 +92,15 @@ class HotPath:
     def flush(self):
         _lib.check(self._L.ur_flush(self._ctx), "ur_flush")
 
+    def time_next_lighting(self, start: "torch.cuda.Event | None", stop: "torch.cuda.Event | None"):
+        """The next Lighting launch carries this event pair on its kernel dispatch (ur_time_next_lighting): after a
+        synchronise, start.elapsed_time(stop) is the dispatch's own duration. The events must have been created with
+        enable_timing=True and recorded at least once (torch creates the HIP event lazily at its first record)."""
+        if start is None:
+            _lib.check(self._L.ur_time_next_lighting(self._ctx, None, None), "ur_time_next_lighting")
+        else:
+            _lib.check(self._L.ur_time_next_lighting(self._ctx, C.c_void_p(start.cuda_event), C.c_void_p(stop.cuda_event)), "ur_time_next_lighting")
+
     # ---- BuildHZB ----
     def build_hzb(self, depth: torch.Tensor, hzb: torch.Tensor, layout: HzbLayout):
         assert depth.dtype == torch.float32 and hzb.dtype == torch.float32 and hzb.numel() >= layout.total

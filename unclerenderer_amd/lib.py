@@ -16,7 +16,7 @@ if os.environ.get("UR_HOTPATH_LIB"):  # diagnostic builds (e.g. the in-kernel-st
     _LIB_PATH = Path(os.environ["UR_HOTPATH_LIB"]).resolve()
 
 UR_OK = 0
-UR_EINVAL, UR_EHIP, UR_ENOMEM, UR_ENODEVICE, UR_EUNSUPPORTED = -1, -2, -3, -4, -5
+UR_EINVAL, UR_EHIP, UR_ENOMEM, UR_ENODEVICE, UR_EUNSUPPORTED, UR_ETIMEOUT = -1, -2, -3, -4, -5, -6
 UR_MAX_HZB_MIPS = 16
 UR_CULL_CONSTANT_DWORDS = 46
 UR_INDIRECT_COMMAND_STRIDE = 64
@@ -107,6 +107,7 @@ UR_FRAME_ASYNC_COMPUTE, UR_FRAME_ASYNC_NO_JOIN, UR_FRAME_TONEMAP, UR_FRAME_TIME_
 UR_FRAME_HZB_TAIL_WITH_LIGHTING = 0x2000
 UR_FRAME_HZB_WITH_LIGHTING = 0x4000
 UR_FRAME_TIME_LIGHTING_RECORD_COST = 0x8000
+UR_FRAME_TIME_LIGHTING_KERNEL = 0x10000
 UR_FRAME_DEFAULT = UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY
 
 assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
@@ -121,7 +122,9 @@ SIGNATURES = {
     "ur_reserve": (C.c_int, [_VP, _U32]),
     "ur_defer_hzb_tail": (C.c_int, [_VP, C.c_int]),
     "ur_flush": (C.c_int, [_VP]),
+    "ur_debug_set_hzb_timeout": (C.c_int, [_VP]),
     "ur_debug_timeline": (C.c_int, [_VP, _VP, _U32]),
+    "ur_time_next_lighting": (C.c_int, [_VP, _VP, _VP]),
     "ur_last_error": (C.c_char_p, []),
     "ur_version": (C.c_char_p, []),
     "ur_hzb_layout": (_U32, [_U32, _U32, C.POINTER(MipDesc), C.POINTER(_U32)]),
@@ -138,6 +141,7 @@ SIGNATURES = {
     "ur_temporal_aa": (C.c_int, [_VP, _VP, _VP, _VP, _F, _U32, _U32, _U32, _U32, _U32]),
     "ur_allgather_rows": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
     "ur_allgather_rows_bytes": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32]),
+    "ur_allgather_rows_bytes_ex": (C.c_int, [_VP, _VP, _VP, _U32, _U32, _U32, _U32, C.c_int]),
     # ur_assets.h
     "ur_dds_parse": (C.c_int, [_VP, C.c_size_t, C.POINTER(DdsInfo)]),
     "ur_dds_texel_count": (C.c_size_t, [C.POINTER(DdsInfo)]),
