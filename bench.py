@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--gather", choices=["ring", "direct"], default="ring",
                     help="N > 1: ring = one all_gather_into_tensor per frame (RCCL's ring / tree); direct = N - 1 grouped send/receive pairs "
                          "per rank, one per xGMI link (unclerenderer_amd/dist.py, ur_allgather_rows_bytes_ex)")
+    ap.add_argument("--light-every", type=int, default=0, help="sample the Lighting dispatch's duration on one timed frame in this many (0 = 2 for runs of up to 64 steps, 8 beyond)")
     ap.add_argument("--no-light-events", action="store_true", help="do not bracket the Lighting pass with events inside the timed region")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="host pacing: the host waits (once every 64 frames) until the GPU is within this many frames of it (the reference "
@@ -229,11 +230,12 @@ def main():
 
     # roofline leg: the Lighting launch of the sampled timed frames carries a HIP event pair ON ITS OWN DISPATCH
     # (ur_time_next_lighting -> hipExtLaunchKernel on the stream the kernel is launched on): the pair's distance is the
-    # dispatch's begin -> end interval as the command processor stamps it — the quantity rocprofv3's kernel trace reports
-    # (profiles/: same command) — and no event-record packet sits in the queue around the kernel. Every frame of a short
-    # run (the driver's --steps 20 gives 20 samples), one in four of a long one.
+    # interval from the end of what precedes the kernel on the stream to the kernel's end as the command processor stamps
+    # them — the quantity rocprofv3's kernel trace reports for the dispatch (profiles/: same command). A sampled frame costs
+    # the queue ~8 us (the marker in front of the kernel): every second frame of a short run (the driver's --steps 20 gives
+    # 10 samples), one in eight of a long one.
     timed_flags = flags if args.no_light_events else (flags | urlib.UR_FRAME_TIME_LIGHTING_KERNEL)
-    light_every = 1 if args.steps <= 64 else 4
+    light_every = args.light_every if args.light_every > 0 else (2 if args.steps <= 64 else 8)
 
     from collections import deque
     pace_marks = deque()

@@ -157,12 +157,15 @@ int ur_debug_set_hzb_timeout(ur_ctx* ctx);
  * switches it off (the default: the kernels then execute one scalar branch for it). */
 int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t capacity_pairs);
 /* Timing: the NEXT ur_deferred_lighting / ur_deferred_lighting_sky launch on the context carries this pair of HIP events
- * (hipEvent_t, created by the caller with timing enabled) on the kernel dispatch itself (hipExtLaunchKernel): after the
- * stream has been synchronised hipEventElapsedTime(start, stop) is the dispatch's own begin -> end interval as the command
- * processor stamps it, the figure rocprofv3's kernel trace reports for it, with no event-record packet in the queue around
- * the kernel. One-shot: the pair is consumed by that launch (by the main kernel of it: a held-back HZB tail that has to go
- * out in front is not timed). The reference's counterpart is the timestamp-query pair FRenderGraph puts around a pass
- * (Source/Render/RenderGraph.cpp:402-406,475-478). NULL, NULL clears a pair that was not consumed. */
+ * (hipEvent_t, created by the caller with timing enabled) on the kernel dispatch (hipExtLaunchKernel): the stop event is
+ * bound to the dispatch's own completion signal, the start event to a marker the runtime puts directly in front of it. After
+ * the stream has been synchronised hipEventElapsedTime(start, stop) is the interval from the end of whatever preceded the
+ * kernel on the stream to the kernel's end as the command processor stamps them: the dispatch's duration including its
+ * launch, which is what rocprofv3's kernel trace reports for it (the profiler serialises dispatches the same way), with no
+ * event record behind the kernel. (A stop event alone is accepted and attached, but measures nothing on ROCm 7.2:
+ * hipEventElapsedTime(e, e) is 0.) One-shot: consumed by that launch (by the main kernel of it: a held-back HZB tail that
+ * has to go out in front is not timed). The reference's counterpart is the timestamp-query pair FRenderGraph puts around a
+ * pass (Source/Render/RenderGraph.cpp:402-406,475-478). NULL, NULL clears what was not consumed. */
 int ur_time_next_lighting(ur_ctx* ctx, void* start_event, void* stop_event);
 const char* ur_last_error(void);
 const char* ur_version(void);

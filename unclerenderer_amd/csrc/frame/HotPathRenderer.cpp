@@ -195,7 +195,7 @@ struct ur_frame
     hipStream_t AsyncStream = nullptr;
     ur_ctx* AsyncCtx = nullptr;
     int DeviceIndex = 0;
-    struct FLightEvents { hipEvent_t first, second, after; bool has_after; };
+    struct FLightEvents { hipEvent_t first, second, after; bool has_after; bool on_dispatch; };
     std::vector<FLightEvents> LightEvents; // ring: an event pair around the Lighting pass + one more right behind it (what a record costs)
     size_t LightHead = 0, LightCount = 0;
     bool bRecordAfter = false; // this frame's bracket gets the third event (UR_FRAME_TIME_LIGHTING_RECORD_COST)
@@ -213,16 +213,19 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
         constexpr size_t kRing = 1024;
         if (f->LightEvents.size() < kRing && begin && f->LightCount == f->LightEvents.size()) {
             hipEvent_t a = nullptr, b = nullptr, c = nullptr;
-            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventCreate(&c) == hipSuccess) f->LightEvents.push_back({a, b, c, false});
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventCreate(&c) == hipSuccess) f->LightEvents.push_back({a, b, c, false, false});
         }
         if (f->LightEvents.empty()) return;
         if (f->bKernelEvents) {
             if (begin) {
                 f->LightHead = f->LightCount % f->LightEvents.size();
+                // start = a marker the runtime puts in front of the kernel, stop = bound to the kernel's own dispatch (its completion
+                // signal's end stamp). (One event alone measures nothing on this runtime: hipEventElapsedTime(e, e) is 0.)
                 (void)ur_time_next_lighting(f->Cmd.GetContext(), f->LightEvents[f->LightHead].first, f->LightEvents[f->LightHead].second);
             } else {
                 (void)ur_time_next_lighting(f->Cmd.GetContext(), nullptr, nullptr); // (a launch that failed validation consumed nothing)
                 f->LightEvents[f->LightHead].has_after = false;
+                f->LightEvents[f->LightHead].on_dispatch = true;
                 ++f->LightCount;
             }
             return;
@@ -234,6 +237,7 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
             (void)hipEventRecord(f->LightEvents[f->LightHead].second, s);
             // a third record with nothing in front of it: second -> after is what one event record adds to the bracket
             f->LightEvents[f->LightHead].has_after = f->bRecordAfter;
+            f->LightEvents[f->LightHead].on_dispatch = false;
             if (f->bRecordAfter) (void)hipEventRecord(f->LightEvents[f->LightHead].after, s);
             ++f->LightCount;
         }

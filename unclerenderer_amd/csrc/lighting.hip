@@ -1441,7 +1441,7 @@ int env_int(const char* name, int dflt)
 template <class K, class... Args>
 void launch_timed(ur_ctx* ctx, K kern, dim3 grid, dim3 block, uint32_t lds, Args... args)
 {
-    if (ctx->time_start != nullptr && ctx->time_stop != nullptr) {
+    if (ctx->time_stop != nullptr) {
         hipExtLaunchKernelGGL(kern, grid, block, lds, ctx->stream, ctx->time_start, ctx->time_stop, 0, args...);
         ctx->time_start = ctx->time_stop = nullptr;
     } else {

@@ -207,7 +207,7 @@ int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t ca
 
 int ur_time_next_lighting(ur_ctx* ctx, void* start_event, void* stop_event)
 {
-    if (!ctx || ((start_event == nullptr) != (stop_event == nullptr))) { set_error("ur_time_next_lighting: the events go together"); return UR_EINVAL; }
+    if (!ctx || (start_event != nullptr && stop_event == nullptr)) { set_error("ur_time_next_lighting: a start event needs a stop event"); return UR_EINVAL; }
     ctx->time_start = static_cast<hipEvent_t>(start_event);
     ctx->time_stop = static_cast<hipEvent_t>(stop_event);
     return UR_OK;

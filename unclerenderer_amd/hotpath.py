@@ -94,12 +94,13 @@ class HotPath:
 
     def time_next_lighting(self, start: "torch.cuda.Event | None", stop: "torch.cuda.Event | None"):
         """The next Lighting launch carries this event pair on its kernel dispatch (ur_time_next_lighting): after a
-        synchronise, start.elapsed_time(stop) is the dispatch's own duration. The events must have been created with
-        enable_timing=True and recorded at least once (torch creates the HIP event lazily at its first record)."""
-        if start is None:
+        synchronise, start.elapsed_time(stop) is the dispatch's duration (launch included). The events must have been created
+        with enable_timing=True and recorded once before (torch creates the HIP event lazily at its first record)."""
+        if stop is None:
             _lib.check(self._L.ur_time_next_lighting(self._ctx, None, None), "ur_time_next_lighting")
         else:
-            _lib.check(self._L.ur_time_next_lighting(self._ctx, C.c_void_p(start.cuda_event), C.c_void_p(stop.cuda_event)), "ur_time_next_lighting")
+            _lib.check(self._L.ur_time_next_lighting(self._ctx, C.c_void_p(start.cuda_event) if start is not None else None, C.c_void_p(stop.cuda_event)),
+                       "ur_time_next_lighting")
 
     # ---- BuildHZB ----
     def build_hzb(self, depth: torch.Tensor, hzb: torch.Tensor, layout: HzbLayout):
