@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does one iteration of the streaming lighting kernel spend its cycles? (diagnostic build with in-kernel stamps)
 
-    UR_BUILD_STAMPS=1 python -m unclerenderer_amd.build --force   # on the build host
+    python tools/build_variants.py --base r02 stamps=-DUR_STAMPS   # on the build host (the round-2 kernel source carries the stamps)
     python tools/stamps_lighting.py                               # on the GPU box
 Reads SHARES, not lengths: the stamps' fences forbid overlaps the real kernel has.
 """

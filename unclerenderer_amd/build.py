@@ -64,8 +64,6 @@ def _stale(target: Path, srcs: list[Path]) -> bool:
 
 def _compile(job) -> Path:
     src, flags, force = job
-    if os.environ.get("UR_BUILD_STAMPS") == "1" and src == "lighting.hip":
-        flags = flags + ["-DUR_STAMPS"]  # diagnostic build: in-kernel cycle stamps (never the shipped configuration)
     srcp = CSRC / src
     obj = OUT / (src.replace("/", "_") + ".o")
     if force or _stale(obj, [srcp] + _deps()):

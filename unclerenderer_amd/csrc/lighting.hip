@@ -32,13 +32,6 @@
 #include <cstring>
 #include <type_traits>
 
-#ifndef UR_ABLATE
-#define UR_ABLATE 0 // diagnostic builds only; see lighting_stream_kernel
-#endif
-#ifndef UR_DMA_NT
-#define UR_DMA_NT 2 // nontemporal hint on the A|B tile DMA: read exactly once (4K: 73.9 -> 72.5 us); the other instruction carries the depth rows, which a riding Build HZB reads again (see tile_dma)
-#endif
-
 namespace {
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -98,7 +91,6 @@ struct LightingParams {
     float skyMie[3];     // LightColor * mieDensity * 0.8 * (1-g^2)/(4 pi)
     float sunAttenuation;
     StreamHot hot;       // streaming kernel: everything one loop iteration reads
-    unsigned long long* stamps; // diagnostic builds (-DUR_STAMPS): per-wave cycle sums of the loop segments
     unsigned long long* timeline; // debug: {first entry, last exit} of this launch (ur_debug_timeline), else null
     // buffers
     const half4_t* A;
@@ -557,26 +549,7 @@ constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradianc
 constexpr uint32_t kLdsHzb = kLdsWork + 16;                         // 80 floats per wave: mip-2 / mip-3 scratch of the waves that walk HZB pieces
 constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
-// Diagnostic / candidate structure: 1 = producer-consumer wave specialisation. The LAST wave of a workgroup is a LOADER: it does
-// nothing but stream the workgroup's tiles, in claim order, into a ring of 56 two-KB slots in LDS (7 chunks of four tiles = 56 DMA
-// instructions in flight), publishing a chunk's slots in `ready[]` once the counted vmcnt says its tiles have landed and refilling
-// them once `done[]` says their readers are through. The other fifteen waves shade: they claim a sequence number, wait for that
-// slot, read it, release it, and never issue a DMA (their in-order vmcnt queue holds gathers and the store only). Measured and
-// not adopted (profiles/r02_ablation.txt block E); kept so that the measurement can be repeated
-// (tools/build_variants.py loader=-DUR_LOADER_WAVE=1; tests/test_isa_guard.py compiles it).
-#ifndef UR_LOADER_WAVE
-#define UR_LOADER_WAVE 0
-#endif
-#ifndef UR_LOADER_VMCNT
-#define UR_LOADER_VMCNT 48 // DMA instructions the loader leaves in flight when it publishes a chunk: 8 per chunk of four tiles
-#endif
-#ifndef UR_LOADER_PRIO
-#define UR_LOADER_PRIO 3
-#endif
-#define UR_STR2(x) #x
-#define UR_STR(x) UR_STR2(x)
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
-[[maybe_unused]] constexpr uint32_t kRingChunks = 14, kRingSlots = 4 * kRingChunks, kRingChunksInFlight = UR_LOADER_VMCNT / 8 + 1; // UR_LOADER_WAVE: the workgroup's tile ring in chunks of four tiles, chunks the loader keeps in flight
 static_assert(kLdsTiles % 16 == 0, "tile buffers are 16-byte aligned");
 
 __device__ __forceinline__ uint32_t lds_address(const void* p)
@@ -633,20 +606,11 @@ __device__ __forceinline__ TileSrc tile_src(P p, uint32_t lane, uint32_t maxRow)
 __device__ __forceinline__ void tile_dma_at(const char* g1, const char* g2 /* biased by -1024 */, uint32_t lds_dst)
 {
     uint32_t keep;
-    // nontemporal hint (UR_DMA_NT): 1 = both instructions, 2 = the A|B one only (the other carries the depth rows, which a riding
-    // Build HZB reads a second time in the same launch)
-#if UR_DMA_NT == 1
-#define UR_DMA_POLICY1 " nt"
-#define UR_DMA_POLICY2 " nt"
-#elif UR_DMA_NT == 2
-#define UR_DMA_POLICY1 " nt"
-#define UR_DMA_POLICY2 ""
-#else
-#define UR_DMA_POLICY1 ""
-#define UR_DMA_POLICY2 ""
-#endif
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" UR_DMA_POLICY1 "\n\t"
-                 "global_load_lds_dwordx4 %2, off offset:1024" UR_DMA_POLICY2 "\n\ts_mov_b32 m0, %0"
+    // The A|B instruction carries the nontemporal hint: those 16 bytes per pixel are read exactly once (4K: 73.9 -> 72.5 us). The
+    // other one does not: it carries the depth rows, which a riding Build HZB reads a second time in the same launch (with the
+    // hint on it that second read comes from memory again: frame 84.4-85.8 instead of 80.5-81.1 us).
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(g1), "v"(g2), "s"(lds_dst)
                  : "memory");
@@ -662,7 +626,7 @@ __device__ __forceinline__ void tile_dma(const TileSrc& s, uint32_t origin /*pix
 template <int MODE, class P>
 __device__ __forceinline__ void tile_prefetch(P p, uint32_t W, uint32_t rows, const TileSrc& full, uint32_t lane, uint32_t tx, uint32_t ty, uint32_t lds_dst)
 {
-    const uint32_t origin = (UR_ABLATE & 64) ? 0u : (ty * 4u) * W + tx * 16u, rowsLeft = rows - ty * 4u; // uniform
+    const uint32_t origin = (ty * 4u) * W + tx * 16u, rowsLeft = rows - ty * 4u; // uniform
     if (rowsLeft >= 4u) tile_dma(full, origin, lds_dst);
     else {
         // cold path (the one partial tile row of a band): the lane index goes through an opaque move so that nothing derived
@@ -713,44 +677,14 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
 }
 
 // WPB waves per workgroup, one workgroup per CU (two of 10 waves at 96 VGPRs were tried: the loop spills).
-#ifdef UR_STAMPS
-// In-kernel stamps (diagnostic build only; cdna_hip_programming.md section 7): one statement = s_memtime + its own wait.
-#define UR_STAMP(var)                                                                        \
-    do {                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");          \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-    } while (0)
-#else
-#define UR_STAMP(var) do { } while (0)
-#endif
-
-// Diagnostic builds only (tools/build_variants.py): UR_ABLATE removes one part of the loop so that its cost can be read off
-// a timing; the output of such a build is wrong by construction. 1: no cube filter (loads kept), 2: no cube lookups at all,
-// 4: no irradiance lookup, 8: no BRDF LUT lookup, 16: no shading at all (DMA in, store out), 32: sRGB decode without the table,
-// 64: every tile is read from and written to the frame's first tile (no HBM traffic: what the arithmetic alone takes).
-// HDR store flavour: 0 plain, 1 nontemporal (nt), 2 write-through (sc1): what the launch leaves dirty in L2 is written back
-// at its end, on the critical path of the next launch.
-#ifndef UR_HDR_STORE
-#define UR_HDR_STORE 2 // write-through: in a loop of its own the launch takes the same time (74.5 / 74.9 / 75.1 us), but the NEXT launch of the frame starts 0.6-0.9 us earlier (frame 80.0-80.4 -> 79.4-79.6 us, four same-box pairs; nt: 79.5-79.8)
-#endif
-#ifndef UR_RIDE_RELEASE_FENCE
-#define UR_RIDE_RELEASE_FENCE 0 // diagnostic: the producer side of the riding HZB hand-off as plain stores + an agent-scope release fence
-#endif
+// HDR stores are write-through (sc1): in a loop of its own the launch takes the same time as with plain or nontemporal stores, but
+// nothing of it is left dirty in L2 for the end of the launch to write back, and the NEXT launch of the frame starts 0.6-0.9 us
+// earlier (frame 80.0-80.4 -> 79.4-79.6 us, four same-box pairs, round 2).
 __device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint32_t lo, uint32_t hi)
 {
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const u32x2_t v = {lo, hi};
-#if UR_HDR_STORE == 2
     asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(byte_offset), "v"(v), "s"(base) : "memory");
-#else
-    UR_GLOBAL u32x2_t* dst = reinterpret_cast<UR_GLOBAL u32x2_t*>((UR_GLOBAL char*)base + byte_offset);
-#if UR_HDR_STORE == 1
-    __builtin_nontemporal_store(v, dst);
-#else
-    *dst = v;
-#endif
-#endif
 }
 
 // The wide launch of a held-back HZB chain, taken along by the lighting workgroups (ur_defer_hzb_tail(ctx, 2)): workgroup g's
@@ -770,13 +704,7 @@ struct HzbRide {
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB, bool RIDE_ALL>
 __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingParams p, ur::HzbTail hzbTail, HzbRide hzbRide)
 {
-    constexpr int kAbl = UR_ABLATE;
     static_assert(MODE != ur::UR_MODE_SKY, "sky-only uses the per-tile kernel");
-#ifdef UR_STAMPS
-    unsigned long long t0 = 0, r0 = 0, tL = 0, tX = 0, r1 = 0, tP1 = 0, tP2 = 0, tP3 = 0, tP4 = 0;
-    UR_STAMP(t0);
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
-#endif
     ur::warm_kernarg<sizeof(LightingParams)>(); // (ur_device.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ur::timeline_entry(p.timeline);
@@ -873,11 +801,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     const uint32_t laneHdr = (row * p.hot.W + col) * 8u;
 
 
-    UR_STAMP(tP1);
-#if !UR_LOADER_WAVE
     if (have0) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
-#endif
-    UR_STAMP(tP2);
     // per-lane part of the pixel's NDC (the tile origin is added per iteration), and the few uniforms that appear as the
     // SECOND scalar operand of an FMA
     const float ndcxL = fmaf((float)col, p.invW2, 0.5f * p.invW2 - 1.0f);
@@ -894,10 +818,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     }
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
-        if (threadIdx.x == 0) { work[0] = UR_LOADER_WAVE ? 0u : 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
-#if UR_LOADER_WAVE
-        if (threadIdx.x < 2u * kRingSlots) reinterpret_cast<uint32_t*>(smem + kLdsTiles + kRingSlots * kTileBytes)[threadIdx.x] = 0u; // ready[56], done[56]
-#endif
+        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
         if (threadIdx.x < irrCount) {
             // value(fx, fy) = t00 + (t10 - t00) fx + (t01 - t00) fy + (t11 - t10 - t01 + t00) fx fy, per channel
@@ -918,80 +839,16 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             if (i < kLutN) lut[i] = float2{(float)(lt[k] & 0xFFFFu) * (1.0f / 65535.0f), (float)(lt[k] >> 16) * (1.0f / 65535.0f)};
         }
     }
-    UR_STAMP(tP3);
     __syncthreads();
-    UR_STAMP(tP4);
     // The second static tile goes out behind the barrier, i.e. behind every first tile of the workgroup: the start-up burst
     // (2 KB per wave and tile, 8 MB over the chip) that the first iteration has to wait for is halved, the other half
     // lands under the first iteration's arithmetic. Its two DMA instructions may stay in flight here.
-#if !UR_LOADER_WAVE
     if (have0 && tile1 < p.hot.numTiles) {
         tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx1, ty1, bufBase + kTileBytes);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t* const ringReady = reinterpret_cast<uint32_t*>(smem + kLdsTiles + kRingSlots * kTileBytes);
-    uint32_t* const ringDone = ringReady + kRingSlots;
-    if (wave == WPB - 1u) {
-        // ---- the loader: chunk k = the workgroup's k-th group of four consecutive tiles (claims 4k .. 4k + 3) -> slots (4k .. 4k + 3) % 56.
-        //      One wave issues an instruction every five cycles or so at best, and the 330 cycles a tile may take at 8 TB/s are few:
-        //      the schedule, the slot hand-shake and the address arithmetic are per CHUNK (one ds_read_b128 of four `done` words,
-        //      one ds_write_b128 of four `ready` words), a tile costs two 64-bit adds, an M0 write and its two DMA instructions.
-        typedef __attribute__((address_space(3))) volatile u32x4_t* LdsV4; // (a volatile access through a generic pointer is a FLAT instruction, which counts in vmcnt)
-        __builtin_amdgcn_s_setprio(UR_LOADER_PRIO);
-        const KParams kpl = fresh_params();
-        const uint32_t ringBase = __builtin_amdgcn_readfirstlane(lds_address(smem + kLdsTiles));
-        const uint32_t step2 = 16u * src.mul2;
-        uint32_t k = 0;
-        for (;; ++k) { // uniform
-            const uint32_t t0 = k * chunkStride + base;
-            if (t0 >= p.hot.numTiles) break;
-            const uint32_t n = min(4u, p.hot.numTiles - t0), slot0 = (k % kRingChunks) * 4u;
-            if (k >= kRingChunks) { // the chunk's slots: their previous occupants (chunk k - 14) must have been read
-                const uint32_t want = (k - kRingChunks) * 4u + 1u;
-                uint32_t spins = 0;
-                for (;;) {
-                    const u32x4_t d = *(LdsV4)(ringDone + slot0);
-                    const bool ok = d.x == want && d.y == want + 1u && d.z == want + 2u && d.w == want + 3u;
-                    if (__builtin_amdgcn_readfirstlane((uint32_t)ok) != 0u) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) break; // (a lost release must not hang the chip)
-                }
-            }
-            const uint32_t ty0 = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)t0 * p.hot.tilesXMagic) >> 32)), tx0 = t0 - ty0 * p.hot.tilesX;
-            if (n == 4u && tx0 + 4u <= p.hot.tilesX && p.hot.rows - ty0 * 4u >= 4u) { // four whole tiles of one tile row
-                const uint32_t origin = (UR_ABLATE & 64) ? 0u : (ty0 * 4u) * p.hot.W + tx0 * 16u;
-                const char* g1 = src.p1 + (uint64_t)origin * 8u;
-                const char* g2 = src.p2 + (uint64_t)origin * src.mul2 - 1024;
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) {
-                    tile_dma_at(g1, g2, ringBase + (slot0 + j) * kTileBytes);
-                    if (!(UR_ABLATE & 64)) { g1 += 128; g2 += step2; }
-                }
-            } else {
-                for (uint32_t j = 0; j < n; ++j) {
-                    const uint32_t t = t0 + j;
-                    const uint32_t tyl = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)t * p.hot.tilesXMagic) >> 32)), txl = t - tyl * p.hot.tilesX;
-                    tile_prefetch<MODE>(kpl, p.hot.W, p.hot.rows, src, lane, txl, tyl, ringBase + (slot0 + j) * kTileBytes);
-                }
-            }
-            if (k + 1u >= kRingChunksInFlight) { // all but the youngest 6 chunks (48 DMA instructions) have landed: publish the oldest of the 7
-                if (n == 4u) asm volatile("s_waitcnt vmcnt(" UR_STR(UR_LOADER_VMCNT) ")" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the workgroup's last chunk may hold fewer instructions)
-                const uint32_t c = k + 1u - kRingChunksInFlight, v = c * 4u + 1u;
-                if (lane == 0) *(LdsV4)(ringReady + (c % kRingChunks) * 4u) = u32x4_t{v, v + 1u, v + 2u, v + 3u};
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (uint32_t c = k >= kRingChunksInFlight ? k - kRingChunksInFlight + 1u : 0u; c < k; ++c) {
-            const uint32_t v = c * 4u + 1u;
-            if (lane == 0) *(LdsV4)(ringReady + (c % kRingChunks) * 4u) = u32x4_t{v, v + 1u, v + 2u, v + 3u};
-        }
-    }
-#endif
 
     // ---- a held-back HZB chain's wide launch rides along: this workgroup's pieces g, g + groups, ... before the tile loop,
     //      dealt over its last `walkers` waves. The waves that walk none join the tile loop at once and the LDS work counter
@@ -1000,8 +857,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     //      tiles), all of them when it is short (a 1/8 band: 22.8 against 37.8 us with one walker).
     //      (RIDE_ALL is a template parameter: with the number of walkers a run-time value the loop spills.)
     if constexpr (WPB == 16) {
-        constexpr uint32_t kWalkers = UR_LOADER_WAVE ? WPB - 1u : WPB; // (the loader wave walks nothing)
-        if (!(UR_LOADER_WAVE && wave == WPB - 1u) && (RIDE_ALL || wave == kWalkers - 1u)) { // uniform
+        constexpr uint32_t kWalkers = WPB;
+        if (RIDE_ALL || wave == kWalkers - 1u) { // uniform
             auto ka = __builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             typedef const __attribute__((address_space(4))) HzbRide* KRide;
@@ -1018,10 +875,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 // producer side of the hand-off: mip 4 was stored write-through (sc1); the wave's stores drained, then ONE
                 // arrival per workgroup. (A release fence instead would write back everything the lighting waves have dirtied
                 // in this XCD's L2: measured, it made the launch 10 us longer.)
-#if UR_RIDE_RELEASE_FENCE
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bool signals = true;
                 if (RIDE_ALL) { // every wave counts itself in LDS behind its drained stores; the one that completes the count signals
@@ -1047,9 +900,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 
     uint32_t parity = 0;
 // (macro: the statement appears in the shading path and in the all-sky path)
-#if UR_LOADER_WAVE
-#define UR_PREFETCH_POINT() do { } while (0)
-#else
 #define UR_PREFETCH_POINT()                                                                                              \
     do {                                                                                                                 \
         if (more1) {                                                                                                     \
@@ -1063,38 +913,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             }                                                                                                            \
         }                                                                                                                \
     } while (0)
-#endif
-#ifdef UR_STAMPS
-    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tE2 = 0, tF = 0, tG = 0, sum0 = 0, sum1 = 0, sum2 = 0, sum3 = 0, sum4 = 0, sum5 = 0, sum6 = 0, iters = 0;
-    UR_STAMP(tL);
-#endif
-#if UR_LOADER_WAVE
-    // a shading wave: sequence numbers from the counter, one ahead (the LDS atomic's latency hides behind a tile)
-    uint32_t seq = 0, seqNext = 0;
-    if (wave != WPB - 1u) {
-        if (lane == 0) seq = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        seq = __builtin_amdgcn_readfirstlane(seq);
-    }
-    while (wave != WPB - 1u) {
-        tile = (seq >> cs) * chunkStride + base + (seq & cmask);
-        if (tile >= p.hot.numTiles) break;
-        const KParams kp = fresh_params();
-        const bool more1 = true;
-        ty = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)tile * p.hot.tilesXMagic) >> 32)); tx = tile - ty * p.hot.tilesX;
-        if (lane == 0) seqNext = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t slot = seq % kRingSlots;
-        {
-            uint32_t spins = 0;
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ringReady + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq + 1u) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) break; // (a lost publication must not hang the chip)
-            }
-            asm volatile("" ::: "memory");
-        }
-        const unsigned char* buf = smem + kLdsTiles + slot * kTileBytes;
-#else
     while (have0) {
-        UR_STAMP(tA);
         const KParams kp = fresh_params(); // cold paths re-read what they need (sky constants, shadow slow path, partial tiles)
         // the tile two steps ahead: claimed here (LDS atomic, long back when the prefetch point needs it)
         uint32_t tile2 = 0xFFFFFFFFu, tx2 = 0, ty2 = 0;
@@ -1103,7 +922,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         uint32_t claim = 0;
         if (more1 && lane == 0) claim = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned char* buf = myTiles + parity * kTileBytes;
-#endif
         const uint2 ga = *reinterpret_cast<const uint2*>(buf + lane * 8u);          // (nx, ny), (nz, -viewZ)
         const uint2 gb = *reinterpret_cast<const uint2*>(buf + 512u + lane * 8u);   // (specular, metallic), (roughness, 1)
         const uint2 gd = *reinterpret_cast<const uint2*>(buf + 1024u + lane * 8u);  // HDR in
@@ -1112,18 +930,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 
         bool sky = false;
         F3 out = f3(0.0f, 0.0f, 0.0f);
-#if UR_LOADER_WAVE
-        const float depthL = MODE == ur::UR_MODE_FUSED ? *reinterpret_cast<const float*>(buf + 1792u + lane * 4u) : 0.0f;
-        // the slot is free once the wave's reads of it have returned
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(ringDone + slot, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
         if (MODE == ur::UR_MODE_FUSED) {
-#if UR_LOADER_WAVE
-            const float depth = depthL;
-#else
             const float depth = *reinterpret_cast<const float*>(buf + 1792u + lane * 4u);
-#endif
             // no pixel of the frame has a sphere depth above skyDepthMax: a wave of nearer geometry skips the per-pixel test
             if (__any(!(depth > p.hot.skyDepthMax))) {
                 const float vx = ndcx * p.hot.skyInvP11, vy = ndcy * p.hot.nSkyInvP22;
@@ -1133,7 +941,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             }
         }
         float outw = 1.0f;
-        if (!(kAbl & 16) && __any(!sky)) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
+        if (__any(!sky)) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
             // ---- decode; every vector in WORLD space (the view matrix is rigid): the camera ray through the pixel is affine in
             //      ndc, the normal is rotated once, and the reflection vector needs no rotation of its own ----------------------
             const float nx = h2f_lo(ga.x), ny = h2f_hi(ga.x), nz = h2f_lo(ga.y), wv = h2f_hi(ga.y);
@@ -1165,8 +973,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const float vR = fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
             const void* env = p.hot.env;
             u32x4_t p0a = {0, 0, 0, 0}, p0b = p0a, p1a = p0a, p1b = p0a;
-            float fx0 = uR, fy0 = vR, fx1 = faceR, fy1 = fl;
-            if (!(kAbl & 2)) {
+            float fx0, fy0, fx1, fy1;
             {
                 const float x = fmaf(uR, e0.x, 0.5f), y = fmaf(vR, e0.x, 0.5f); // bordered coordinates in [0.5, N + 0.5]
                 const float i0 = floorf(x), j0 = floorf(y);
@@ -1182,7 +989,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 8u;
                 p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB1));
-            }
             }
             const F3 Nw = N;
             const float faceN = __builtin_amdgcn_cubeid(Nw.x, Nw.y, Nw.z);
@@ -1221,15 +1027,13 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
                 sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
             }
-            UR_STAMP(tB);
             // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
             // table byte offsets straight from the packed texel: (c << 2) & 0x3FC, (c >> 6) & 0x3FC, (c >> 14) & 0x3FC
             const unsigned char* srgbB = reinterpret_cast<const unsigned char*>(srgb);
-            const F3 albedo = (kAbl & 32) ? f3((float)(gc & 0xFFu) * (1.0f / 255.0f), (float)((gc >> 8) & 0xFFu) * (1.0f / 255.0f), (float)((gc >> 16) & 0xFFu) * (1.0f / 255.0f))
-                                          : f3(*reinterpret_cast<const float*>(srgbB + ((gc << 2) & 0x3FCu)), *reinterpret_cast<const float*>(srgbB + ((gc >> 6) & 0x3FCu)),
-                                               *reinterpret_cast<const float*>(srgbB + ((gc >> 14) & 0x3FCu)));
-            float ba = NdotV, bb = roughness;
-            if (!(kAbl & 8)) {
+            const F3 albedo = f3(*reinterpret_cast<const float*>(srgbB + ((gc << 2) & 0x3FCu)), *reinterpret_cast<const float*>(srgbB + ((gc >> 6) & 0x3FCu)),
+                                 *reinterpret_cast<const float*>(srgbB + ((gc >> 14) & 0x3FCu)));
+            float ba, bb;
+            {
                 // bordered coordinates: x in [0.5, W + 0.5] (NdotV is saturated), y clamped likewise (roughness is not)
                 const float x = fmaf(NdotV, (float)kLutW, 0.5f);
                 const float y = __builtin_amdgcn_fmed3f(fmaf(roughness, (float)kLutH, 0.5f), 0.5f, (float)kLutH + 0.5f);
@@ -1242,8 +1046,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 ba = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
                 bb = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
             }
-            F3 irradiance = (kAbl & 4) ? f3(uN, vN, faceN) : f3(0.0f, 0.0f, 0.0f);
-            if (IRR_LDS && !(kAbl & 4)) {
+            F3 irradiance = f3(0.0f, 0.0f, 0.0f);
+            if (IRR_LDS) {
                 const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
                 const float fx = x - i0, fy = y - j0;
@@ -1282,7 +1086,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 p5 = om2 * om2 * om;
             }
             float kdm = 1.0f - metallic;
-            UR_STAMP(tC);
             // the math above is wanted BEFORE the first wait on a gather, not sunk behind it
             asm volatile("" : "+v"(scs), "+v"(p5), "+v"(kdm), "+v"(ba), "+v"(bb), "+v"(irradiance.x), "+v"(irradiance.y), "+v"(irradiance.z));
             __builtin_amdgcn_sched_barrier(0);
@@ -1309,17 +1112,12 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             need(p0a, p0b, p1a, p1b);
             if (!IRR_LDS) need(pia, pib, pia, pib);
             __builtin_amdgcn_sched_barrier(0);
-            UR_STAMP(tD);
             // hipcc has no load of its own in flight here: the DMA for the tile two steps ahead goes into the buffer just read.
             // The vmcnt(0) retires every older vector-memory operation of the wave, in particular the DMA issued at the previous
             // iteration's prefetch point: the tile the NEXT iteration reads is in LDS from here on.
-#if !UR_LOADER_WAVE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            UR_STAMP(tE);
             UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
-            UR_STAMP(tE2);
             // ---- filter, combine ---------------------------------------------------------------------------------------------------
             const float sh_l = shadow * NdotL;
             F3 prefiltered;
@@ -1332,9 +1130,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 float b10 = b0 * fx1, b00 = b0 - b10, b11 = b1 * fx1, b01 = b1 - b11;
                 asm volatile("" : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11));
                 float x, y, z;
-                if (kAbl & 3) {
-                    x = h2f_lo(p0a.x) + h2f_lo(p0b.x); y = h2f_lo(p1a.x) + h2f_lo(p1b.x); z = fx0 + fy0 + fx1 + fy1;
-                } else {
                 x = mul_lo(p0a.x, a00); y = mul_hi(p0a.x, a00); z = mul_lo(p0a.y, a00);
                 x = mix_lo(x, p0a.z, a10); y = mix_hi(y, p0a.z, a10); z = mix_lo(z, p0a.w, a10);
                 x = mix_lo(x, p0b.x, a01); y = mix_hi(y, p0b.x, a01); z = mix_lo(z, p0b.y, a01);
@@ -1343,7 +1138,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 x = mix_lo(x, p1a.z, b10); y = mix_hi(y, p1a.z, b10); z = mix_lo(z, p1a.w, b10);
                 x = mix_lo(x, p1b.x, b01); y = mix_hi(y, p1b.x, b01); z = mix_lo(z, p1b.y, b01);
                 x = mix_lo(x, p1b.z, b11); y = mix_hi(y, p1b.z, b11); z = mix_lo(z, p1b.w, b11);
-                }
                 prefiltered = f3(x, y, z);
                 if (!IRR_LDS) {
                     CubeTaps t;
@@ -1373,34 +1167,21 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             }
         } else {
             __builtin_amdgcn_sched_barrier(0);
-#if !UR_LOADER_WAVE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
         }
-        UR_STAMP(tG);
         if (ty * 4u + row < p.hot.rows) { // false only in the rows a partial bottom tile hangs over the band
             half4_t o;
             o.x = (_Float16)out.x; o.y = (_Float16)out.y; o.z = (_Float16)out.z; o.w = (_Float16)outw;
             uint2 ob;
             __builtin_memcpy(&ob, &o, 8);
-            store_hdr(p.hot.hdr, ((kAbl & 64) ? 0u : ((ty * 4u) * p.hot.W + tx * 16u) * 8u) + laneHdr, ob.x, ob.y);
+            store_hdr(p.hot.hdr, ((ty * 4u) * p.hot.W + tx * 16u) * 8u + laneHdr, ob.x, ob.y);
         }
-#ifdef UR_STAMPS
-        UR_STAMP(tF);
-        if (tE != 0) { sum0 += tB - tA; sum1 += tC - tB; sum2 += tD - tC; sum3 += tE - tD; sum4 += tF - tE; sum5 += tE2 - tE; sum6 += tF - tG; iters += 1; }
-        tE = 0;
-#endif
-#if UR_LOADER_WAVE
-        seq = __builtin_amdgcn_readfirstlane(seqNext);
-        (void)more1; (void)parity; (void)tile1; (void)tx1; (void)ty1;
-#else
         if (!more1) break;
         tile = tile1; tile1 = tile2; // tile2 stays 0xFFFFFFFF when nothing was left to claim
         tx = tx1; ty = ty1; tx1 = tx2; ty1 = ty2;
         parity ^= 1u;
-#endif
     }
 #undef UR_PREFETCH_POINT
     if (p.timeline != nullptr) { // debug timeline: the workgroup's LAST wave to leave the loop stamps the exit (uniform branch)
@@ -1408,16 +1189,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         if (lane == 0) left = __hip_atomic_fetch_add(work + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ur::timeline_exit(p.timeline, lane == 0 && left == WPB - 1u);
     }
-#ifdef UR_STAMPS
-    if (p.stamps && lane == 0) {
-        unsigned long long* o = p.stamps + (size_t)(blockIdx.x * WPB + wave) * 16u;
-        UR_STAMP(tX);
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
-        o[0] = sum0; o[1] = sum1; o[2] = sum2; o[3] = sum3; o[4] = sum4; o[5] = iters | ((r1 - r0) << 16);
-        o[8] = tP1 - t0; o[9] = tP2 - t0; o[10] = tP3 - t0; o[11] = tP4 - t0; o[12] = t0; o[13] = sum5; o[14] = sum6;
-        o[6] = tL - t0; o[7] = tX - t0; // prologue and whole-kernel cycles of this wave; [5] >> 16 = the same span in 100 MHz ticks
-    }
-#endif
 }
 
 void mat4_mul(const float* a, const float* b, float* o)
@@ -1462,21 +1233,12 @@ void launch_tiled(ur_ctx* ctx, const LightingParams& p)
     else launch_timed(ctx, lighting_kernel<MODE, SHADOWS, TW, 4>, dim3(tilesX, tilesY), dim3(256), 0u, p);
 }
 
-#ifdef UR_STAMPS
-unsigned long long* g_stamps = nullptr;
-constexpr size_t kStampWaves = 8192;
-#endif
 
 template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk is filled in here */)
 {
     typedef void (*kernel_t)(LightingParams, ur::HzbTail, HzbRide);
-#ifdef UR_STAMPS
-    if (!g_stamps) UR_HIP_TRY(hipMalloc(&g_stamps, kStampWaves * 16 * sizeof(unsigned long long)));
-    UR_HIP_TRY(hipMemsetAsync(g_stamps, 0, kStampWaves * 16 * sizeof(unsigned long long), ctx->stream));
-    p.stamps = g_stamps;
-#endif
-    constexpr uint32_t lds = UR_LOADER_WAVE ? kLdsTiles + kRingSlots * kTileBytes + 2u * kRingSlots * 4u : kLdsTiles + WPB * 2u * kTileBytes;
+    constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
     p.timeline = ur::next_timeline_pair(ctx);
     // MaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: one flag per instantiation and device
     static bool attr_set[2][64] = {};
@@ -1526,7 +1288,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
     static const int chunk_shift = env_int("UR_LIGHTING_CHUNK_SHIFT", 2); // 4K: chunks of 16 / 4 / 1 tiles -> 75.4 / 74.6 / 79.1 us
-    h.chunkShift = UR_LOADER_WAVE ? 2u : (uint32_t)std::min(std::max(chunk_shift, 0), 4); // (the loader wave moves chunks of four tiles)
+    h.chunkShift = (uint32_t)std::min(std::max(chunk_shift, 0), 4);
     const bool ride_all = ride.pieces != 0u && ride.walkers > 1u;
     const kernel_t kern = ride_all ? static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, true>)
                                    : static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, false>);
@@ -1550,15 +1312,6 @@ int launch_stream(ur_ctx* ctx, const LightingParams& p)
 
 } // namespace
 
-#ifdef UR_STAMPS
-// diagnostic builds only: the per-wave segment sums of the last streaming launch (16 u64 per wave)
-extern "C" int ur_debug_stamps(unsigned long long* out, unsigned int waves)
-{
-    if (!g_stamps || waves > kStampWaves) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -2;
-    return hipMemcpy(out, g_stamps, (size_t)waves * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
-}
-#endif
 
 namespace ur {
 
