@@ -25,6 +25,10 @@
 
 #include <hip/hip_ext.h>
 
+#ifndef UR_PK
+#define UR_PK 1 // TEMPORARY (round-3 experiment): which groups of the loop use the dieted / packed forms
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
@@ -143,6 +147,14 @@ __device__ __forceinline__ float3u ld<float3u>(const void* base, uint32_t byte_o
     const f32x3_t v = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)base + byte_offset);
     return {v.x, v.y, v.z};
 }
+
+// Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of one operation on an even-aligned register
+// pair; a scalar operand is broadcast through op_sel at no cost). A packed instruction holds the SIMD's issue port ~5 cycles
+// against ~3.25 for a plain one (tools/microbench/valu_rate.hip): 2.5 per operation where BOTH halves are wanted.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2_t f2(float x, float y) { return f2_t{x, y}; }
+__device__ __forceinline__ f2_t splat(float x) { return f2_t{x, x}; }
+__device__ __forceinline__ f2_t pk_fma(f2_t a, f2_t b, f2_t c) { return __builtin_elementwise_fma(a, b, c); }
 
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { return {x, y, z}; }
@@ -668,6 +680,25 @@ __device__ __forceinline__ float gt_step(float cmpBig, float t, float negBig /* 
     return r;
 }
 
+// Wave-uniform conditions as SGPR integers. A `bool` that is defined in one basic block and tested or negated in another is a
+// lane mask to hipcc, and every such use goes through a VGPR (v_cndmask_b32 0/1 + v_cmp_ne_u32: the loop had four such
+// pairs, and a v_cndmask_b32 holds the issue port ~22 cycles on gfx950, tools/microbench/valu_rate.hip). The ballot is taken
+// where the comparison is made; what crosses blocks is a 32-bit scalar.
+__device__ __forceinline__ uint32_t flag_any(bool pred)
+{
+    const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
+    uint32_t r;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
+__device__ __forceinline__ uint32_t flag_all(bool pred) // (every lane of the wave is active where this is used)
+{
+    const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
+    uint32_t r;
+    asm("s_cmp_eq_u64 %1, -1\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(m) : "scc");
+    return r;
+}
+
 struct __attribute__((aligned(16))) MipEntry { float Nf, Ef, EEf, offf; uint32_t rowBytes, pad0, pad1, pad2; };
 
 // input-only "these registers are needed here": hipcc puts the s_waitcnt of pending loads in front of the statement
@@ -816,6 +847,10 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     for (int k = 0; k < 3; ++k) {
         WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); shT[k] = vreg(p.hot.shT[k]); lightRGB[k] = vreg(p.hot.lightRGB[k]);
     }
+    // the x, y halves of the same constants as packed pairs (the same registers: a pair is two neighbouring VGPRs)
+    constexpr int PK = UR_PK;
+    const f2_t Rxy[3] = {f2(R[0], R[1]), f2(R[3], R[4]), f2(R[6], R[7])};
+    const f2_t WCxy = f2(WC[0], WC[1]), shCxy = f2(shC[0], shC[1]), shTxy = f2(shT[0], shT[1]), lightRGBxy = f2(lightRGB[0], lightRGB[1]);
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
         if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
@@ -824,8 +859,13 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             // value(fx, fy) = t00 + (t10 - t00) fx + (t01 - t00) fy + (t11 - t10 - t01 + t00) fx fy, per channel
             const float a[3] = {(float)ih.x, (float)ih.y, (float)ih.z}, b[3] = {(float)ih10.x, (float)ih10.y, (float)ih10.z};
             const float c[3] = {(float)ih01.x, (float)ih01.y, (float)ih01.z}, d[3] = {(float)ih11.x, (float)ih11.y, (float)ih11.z};
+            // one 64-byte entry per cell: (a.x a.y b.x b.y | c.x c.y d.x d.y | a.z b.z c.z d.z): x and y are evaluated as a packed pair
+            float A_[3], B_[3], C_[3], D_[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) irrT[threadIdx.x * 4u + k] = float4a{a[k], b[k] - a[k], c[k] - a[k], (d[k] - b[k]) - (c[k] - a[k])};
+            for (int k = 0; k < 3; ++k) { A_[k] = a[k]; B_[k] = b[k] - a[k]; C_[k] = c[k] - a[k]; D_[k] = (d[k] - b[k]) - (c[k] - a[k]); }
+            irrT[threadIdx.x * 4u + 0u] = float4a{A_[0], A_[1], B_[0], B_[1]};
+            irrT[threadIdx.x * 4u + 1u] = float4a{C_[0], C_[1], D_[0], D_[1]};
+            irrT[threadIdx.x * 4u + 2u] = float4a{A_[2], B_[2], C_[2], D_[2]};
         }
         if (threadIdx.x < 17u) {
             const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
@@ -902,23 +942,26 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 // (macro: the statement appears in the shading path and in the all-sky path)
 #define UR_PREFETCH_POINT()                                                                                              \
     do {                                                                                                                 \
-        if (more1) {                                                                                                     \
-            const uint32_t c = __builtin_amdgcn_readfirstlane(claim);                                                    \
-            tile2 = (c >> cs) * chunkStride + base + (c & cmask);                                                        \
-            more2 = tile2 < p.hot.numTiles;                                                                                 \
-            if (more2) {                                                                                                 \
-                ty2 = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)tile2 * p.hot.tilesXMagic) >> 32));              \
-                tx2 = tile2 - ty2 * p.hot.tilesX;                                                                           \
-                tile_prefetch<MODE>(kp, p.hot.W, p.hot.rows, src, lane, tx2, ty2, bufBase + parity * kTileBytes);              \
-            }                                                                                                            \
+        const uint32_t c = __builtin_amdgcn_readfirstlane(claim); /* 0 when nothing was claimed (more1 == 0) */            \
+        tile2 = (c >> cs) * chunkStride + base + (c & cmask);                                                            \
+        uint32_t in_band;                                                                                                \
+        asm("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(in_band) : "s"(tile2), "s"(p.hot.numTiles) : "scc"); \
+        more2 = in_band & more1; /* scalar AND: no branch on more1 here */                                                \
+        if (more2) {                                                                                                     \
+            ty2 = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)tile2 * p.hot.tilesXMagic) >> 32));                  \
+            tx2 = tile2 - ty2 * p.hot.tilesX;                                                                               \
+            tile_prefetch<MODE>(kp, p.hot.W, p.hot.rows, src, lane, tx2, ty2, bufBase + parity * kTileBytes);                  \
+        } else {                                                                                                         \
+            tile2 = 0xFFFFFFFFu; /* nothing was left to claim */                                                          \
         }                                                                                                                \
     } while (0)
     while (have0) {
         const KParams kp = fresh_params(); // cold paths re-read what they need (sky constants, shadow slow path, partial tiles)
         // the tile two steps ahead: claimed here (LDS atomic, long back when the prefetch point needs it)
         uint32_t tile2 = 0xFFFFFFFFu, tx2 = 0, ty2 = 0;
-        bool more2 = false;
-        const bool more1 = tile1 < p.hot.numTiles; // uniform
+        uint32_t more2 = 0u;
+        uint32_t more1; // uniform, kept as a scalar integer (see flag_any)
+        asm("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(more1) : "s"(__builtin_amdgcn_readfirstlane(tile1)), "s"(p.hot.numTiles) : "scc");
         uint32_t claim = 0;
         if (more1 && lane == 0) claim = __hip_atomic_fetch_add(work, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned char* buf = myTiles + parity * kTileBytes;
@@ -929,6 +972,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         const float ndcx = fmaf((float)(tx * 16u), p.hot.invW2, ndcxL), ndcy = fmaf((float)(p.hot.row0 + ty * 4u) + rowh, p.hot.invH2, -1.0f);
 
         bool sky = false;
+        uint32_t all_sky = 0u; // uniform: every pixel of the tile is sky
         F3 out = f3(0.0f, 0.0f, 0.0f);
         if (MODE == ur::UR_MODE_FUSED) {
             const float depth = *reinterpret_cast<const float*>(buf + 1792u + lane * 4u);
@@ -937,31 +981,46 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const float vx = ndcx * p.hot.skyInvP11, vy = ndcy * p.hot.nSkyInvP22;
                 // sphere depth (Near/R) * |(vx, vy, 1)| >= depth, compared squared (depth is in [0,1]): no square root
                 sky = p.hot.skyNearOverR2 * fmaf(vx, vx, fmaf(vy, vy, 1.0f)) >= depth * depth;
+                all_sky = flag_all(sky);
                 if (sky) out = sky_pixel(kp, vx, vy);
             }
         }
         float outw = 1.0f;
-        if (__any(!sky)) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
+        if (!all_sky) { // wave-uniform: sky lanes shade whatever they loaded and drop the result
             // ---- decode; every vector in WORLD space (the view matrix is rigid): the camera ray through the pixel is affine in
-            //      ndc, the normal is rotated once, and the reflection vector needs no rotation of its own ----------------------
+            //      ndc, the normal is rotated once, and the reflection vector needs no rotation of its own. x and y of a vector
+            //      travel as a packed pair wherever both take the same operation -----------------------------------------------
             const float nx = h2f_lo(ga.x), ny = h2f_hi(ga.x), nz = h2f_lo(ga.y), wv = h2f_hi(ga.y);
             const float nr = rsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx))); // normalize(0) = NaN, as in the reference
-            const F3 N = rot(f3(nx * nr, ny * nr, nz * nr), R);
+            f2_t Nxy;
+            float Nz;
+            if (PK & 8) {
+                Nxy = pk_fma(splat(nz), Rxy[2], pk_fma(splat(ny), Rxy[1], splat(nx) * Rxy[0])) * splat(nr);
+                Nz = fmaf(nz, R[8], fmaf(ny, R[5], nx * R[2])) * nr;
+            } else {
+                const F3 N = rot(f3(nx * nr, ny * nr, nz * nr), R);
+                Nxy = f2(N.x, N.y); Nz = N.z;
+            }
             const float viewZ = -wv;
             const float spec0 = h2f_lo(gb.x), metallic = h2f_hi(gb.x), roughness = h2f_lo(gb.y);
             const F3 L = f3(p.hot.Lw[0], p.hot.Lw[1], p.hot.Lw[2]);
-            const float NdotL = sat(dot(N, L));
-            const F3 Wd = f3(fmaf(ndcx, p.hot.WA[0], fmaf(ndcy, p.hot.WB[0], WC[0])), fmaf(ndcx, p.hot.WA[1], fmaf(ndcy, p.hot.WB[1], WC[1])),
-                             fmaf(ndcx, p.hot.WA[2], fmaf(ndcy, p.hot.WB[2], WC[2]))); // (ra, rb, 1) * ViewInverse3x3
+            const float NdotLraw = fmaf(Nz, L.z, fmaf(Nxy.y, L.y, Nxy.x * L.x));
+            const float NdotL = sat(NdotLraw);
+            f2_t Wxy;
+            if (PK & 8) Wxy = pk_fma(splat(ndcx), f2(p.hot.WA[0], p.hot.WA[1]), pk_fma(splat(ndcy), f2(p.hot.WB[0], p.hot.WB[1]), WCxy));
+            else Wxy = f2(fmaf(ndcx, p.hot.WA[0], fmaf(ndcy, p.hot.WB[0], WC[0])), fmaf(ndcx, p.hot.WA[1], fmaf(ndcy, p.hot.WB[1], WC[1])));
+            const float Wz = fmaf(ndcx, p.hot.WA[2], fmaf(ndcy, p.hot.WB[2], WC[2])); // (ra, rb, 1) * ViewInverse3x3
             // V = normalize(-viewPos) = -sign(viewZ) Wd / |Wd|; sign(-viewZ) is the stored sign of A.w
-            const float vs = __builtin_copysignf(rsq(dot(Wd, Wd)), wv);
-            const F3 V = f3(Wd.x * vs, Wd.y * vs, Wd.z * vs);
-            const float NdotVraw = dot(N, V);
+            const float vs = __builtin_copysignf(rsq(fmaf(Wz, Wz, fmaf(Wxy.y, Wxy.y, Wxy.x * Wxy.x))), wv);
+            const f2_t Vxy = (PK & 8) ? Wxy * splat(vs) : f2(Wxy.x * vs, Wxy.y * vs);
+            const float Vz = Wz * vs;
+            const float NdotVraw = fmaf(Nz, Vz, fmaf(Nxy.y, Vxy.y, Nxy.x * Vxy.x));
             const float NdotV = sat(NdotVraw);
             // ---- global gathers: the two prefiltered mips (bordered cube, addresses in fp32: every integer multiply would hold
             //      the issue port), then the shadow block ------------------------------------------------------------------------
             const float t2 = 2.0f * NdotVraw;
-            const F3 Rw = f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z));
+            const f2_t Rxyw = (PK & 8) ? pk_fma(splat(t2), Nxy, -Vxy) : f2(fmaf(t2, Nxy.x, -Vxy.x), fmaf(t2, Nxy.y, -Vxy.y));
+            const F3 Rw = f3(Rxyw.x, Rxyw.y, fmaf(t2, Nz, -Vz));
             const float lvl = __builtin_amdgcn_fmed3f(roughness * p.hot.maxMip, 0.0f, p.hot.envMaxLevel);
             const float fl = __builtin_amdgcn_fractf(lvl);
             const MipEntry* me = mipT + (uint32_t)lvl;
@@ -969,36 +1028,37 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const uint32_t rowB0 = me[0].rowBytes, rowB1 = me[1].rowBytes;
             const float faceR = __builtin_amdgcn_cubeid(Rw.x, Rw.y, Rw.z);
             const float invR = rcp(fabsf(__builtin_amdgcn_cubema(Rw.x, Rw.y, Rw.z)));
-            const float uR = fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
-            const float vR = fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f);
+            f2_t uvR;
+            if (PK & 16) uvR = pk_fma(f2(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), __builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z)), splat(invR), splat(0.5f));
+            else uvR = f2(fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f), fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f));
             const void* env = p.hot.env;
-            u32x4_t p0a = {0, 0, 0, 0}, p0b = p0a, p1a = p0a, p1b = p0a;
-            float fx0, fy0, fx1, fy1;
+            u32x4_t p0a, p0b, p1a, p1b;
+            f2_t f0, f1; // (fx, fy) of the two mips
             {
-                const float x = fmaf(uR, e0.x, 0.5f), y = fmaf(vR, e0.x, 0.5f); // bordered coordinates in [0.5, N + 0.5]
-                const float i0 = floorf(x), j0 = floorf(y);
-                fx0 = x - i0; fy0 = y - j0;
+                const f2_t xy = (PK & 16) ? pk_fma(uvR, splat(e0.x), splat(0.5f)) : f2(fmaf(uvR.x, e0.x, 0.5f), fmaf(uvR.y, e0.x, 0.5f)); // bordered coordinates in [0.5, N + 0.5]
+                const float i0 = floorf(xy.x), j0 = floorf(xy.y);
+                f0 = (PK & 16) ? xy - f2(i0, j0) : f2(xy.x - i0, xy.y - j0);
                 const uint32_t o = (uint32_t)(fmaf(faceR, e0.z, fmaf(j0, e0.y, i0)) + e0.w) * 8u;
                 p0a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 p0b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB0));
             }
             {
-                const float x = fmaf(uR, e1.x, 0.5f), y = fmaf(vR, e1.x, 0.5f);
-                const float i0 = floorf(x), j0 = floorf(y);
-                fx1 = x - i0; fy1 = y - j0;
+                const f2_t xy = (PK & 16) ? pk_fma(uvR, splat(e1.x), splat(0.5f)) : f2(fmaf(uvR.x, e1.x, 0.5f), fmaf(uvR.y, e1.x, 0.5f));
+                const float i0 = floorf(xy.x), j0 = floorf(xy.y);
+                f1 = (PK & 16) ? xy - f2(i0, j0) : f2(xy.x - i0, xy.y - j0);
                 const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 8u;
                 p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB1));
             }
-            const F3 Nw = N;
-            const float faceN = __builtin_amdgcn_cubeid(Nw.x, Nw.y, Nw.z);
-            const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nw.x, Nw.y, Nw.z)));
-            const float uN = fmaf(__builtin_amdgcn_cubesc(Nw.x, Nw.y, Nw.z), invN, 0.5f);
-            const float vN = fmaf(__builtin_amdgcn_cubetc(Nw.x, Nw.y, Nw.z), invN, 0.5f);
+            const float faceN = __builtin_amdgcn_cubeid(Nxy.x, Nxy.y, Nz);
+            const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nxy.x, Nxy.y, Nz)));
+            f2_t uvN;
+            if (PK & 16) uvN = pk_fma(f2(__builtin_amdgcn_cubesc(Nxy.x, Nxy.y, Nz), __builtin_amdgcn_cubetc(Nxy.x, Nxy.y, Nz)), splat(invN), splat(0.5f));
+            else uvN = f2(fmaf(__builtin_amdgcn_cubesc(Nxy.x, Nxy.y, Nz), invN, 0.5f), fmaf(__builtin_amdgcn_cubetc(Nxy.x, Nxy.y, Nz), invN, 0.5f));
             u32x4_t pia = {0, 0, 0, 0}, pib = {0, 0, 0, 0};
             float fxi = 0.0f, fyi = 0.0f;
             if (!IRR_LDS) {
-                const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
+                const float x = fmaf(uvN.x, p.hot.irrNf, 0.5f), y = fmaf(uvN.y, p.hot.irrNf, 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
                 fxi = x - i0; fyi = y - j0;
                 const uint32_t o = (uint32_t)(fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0)) + p.hot.irrOfff) * 8u;
@@ -1006,109 +1066,125 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 pib = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + p.hot.irrRowBytes));
             }
             // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF (direct = 0).
-            const bool wave_direct = __any(NdotL > 0.0f);
-            const bool wave_lit = SHADOWS && wave_direct;
+            const uint32_t wave_direct = flag_any(NdotL > 0.0f);
             f32x3_t sa = {0, 0, 0}, sb = {0, 0, 0}, sc3 = {0, 0, 0};
-            float xa = 0.0f, ya = 0.0f, cmp = 0.0f, sfx = 0.0f, sfy = 0.0f;
-            bool fast = true;
-            if (wave_lit) {
-                // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) = viewZ * (affine in ndc) + constant
-                xa = fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), shT[0]);
-                ya = fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), shT[1]);
-                cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), shT[2]);
-                const float xa0 = floorf(xa), ya0 = floorf(ya);
-                sfx = xa - xa0; sfy = ya - ya0;
-                // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
-                const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, p.hot.shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, p.hot.shadowHm3);
-                fast = ic == xa0 && jc == ya0;
-                const uint32_t o0 = (uint32_t)fmaf(jc, p.hot.shadowWf, ic) * 4u, o1 = o0 + p.hot.shadowRowBytes, o2 = o1 + p.hot.shadowRowBytes;
-                const float* smap = p.hot.shadow;
-                sa = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o0);
-                sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
-                sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
+            f2_t xya = f2(0.0f, 0.0f), sf = f2(0.0f, 0.0f); // (su * W - 0.5, sv * H - 0.5) and its fraction
+            float cmp = 0.0f;
+            uint32_t any_slow = 0u; // uniform: some pixel's 3x3 block touches the border of the map (or lies outside it)
+            float scs = 0.0f, p5 = 0.0f;
+            // ONE uniform region for everything only a lit wave needs ahead of the gather wait: the shadow taps' issue (the last
+            // gathers of the iteration) and EvaluatePBR's D, G, F terms (PBRCommon.hlsl:24-48), which run while the gathers are
+            // in flight. A wave without a lit pixel has direct = 0 whatever they are.
+            if (wave_direct) {
+                if (SHADOWS) {
+                    // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) = viewZ * (affine in ndc) + constant
+                    if (PK & 16) xya = pk_fma(splat(viewZ), pk_fma(splat(ndcx), f2(p.hot.shA[0], p.hot.shA[1]), pk_fma(splat(ndcy), f2(p.hot.shB[0], p.hot.shB[1]), shCxy)), shTxy);
+                    else xya = f2(fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), shT[0]), fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), shT[1]));
+                    cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), shT[2]);
+                    const float xa0 = floorf(xya.x), ya0 = floorf(xya.y);
+                    sf = (PK & 16) ? xya - f2(xa0, ya0) : f2(xya.x - xa0, xya.y - ya0);
+                    // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
+                    const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, p.hot.shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, p.hot.shadowHm3);
+                    any_slow = flag_any(ic != xa0) | flag_any(jc != ya0); // (each ballot straight off its comparison)
+                    const uint32_t o0 = (uint32_t)fmaf(jc, p.hot.shadowWf, ic) * 4u, o1 = o0 + p.hot.shadowRowBytes, o2 = o1 + p.hot.shadowRowBytes;
+                    const float* smap = p.hot.shadow;
+                    sa = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o0);
+                    sb = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o1);
+                    sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
+                }
+                float NdotH, om;
+                if (PK & 1) {
+                    // V and L are unit vectors: |V + L|^2 = 2 + 2 V.L, N.(V + L) = N.V + N.L, V.(V + L) = 1 + V.L
+                    const float VL = fmaf(Vz, L.z, fmaf(Vxy.y, L.y, Vxy.x * L.x));
+                    const float hr = rsq(fmaf(VL, 2.0f, 2.0f));
+                    NdotH = sat((NdotVraw + NdotLraw) * hr);
+                    om = fmaf(-VL, hr, 1.0f - hr); // 1 - VdotH, VdotH = (1 + V.L) / |V + L| in [0,1]: saturate is the identity up to rounding
+                } else {
+                    const F3 V = f3(Vxy.x, Vxy.y, Vz), N = f3(Nxy.x, Nxy.y, Nz);
+                    F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
+                    const float hr = rsq(dot(Hv, Hv));
+                    NdotH = sat(dot(N, Hv) * hr);
+                    om = 1.0f - dot(V, Hv) * hr;
+                }
+                const float alpha = roughness * roughness;
+                const float alpha2 = alpha * alpha;
+                const float denom = fmaf(NdotH * NdotH, alpha2 - 1.0f, 1.0f);
+                float k = roughness + 1.0f;
+                k = (k * k) * 0.125f;
+                const float omk = 1.0f - k;
+                const float gv = fmaf(NdotV, omk, k), gl = fmaf(NdotL, omk, k);
+                // max(4 x, 1e-4) = 4 max(x, 1e-4 / 4) exactly (power-of-two scaling)
+                const float nvl = NdotV * NdotL;
+                if (PK & 1) {
+                    // D G / max(4 NdotL NdotV, 1e-4) with ONE reciprocal: every factor of the denominator is >= 1e-4 and <= ~40, their
+                    // product stays far inside the fp32 range
+                    scs = (alpha2 * nvl) * rcp((fmaxf(3.14159265f * denom * denom, 1e-4f) * (gv * gl)) * (4.0f * fmaxf(nvl, 1e-4f * 0.25f)));
+                } else {
+                    const float D = alpha2 * rcp(fmaxf(3.14159265f * denom * denom, 1e-4f));
+                    scs = (D * nvl) * rcp((gv * gl) * (4.0f * fmaxf(nvl, 1e-4f * 0.25f)));
+                }
+                const float om2 = om * om;
+                p5 = om2 * om2 * om;
             }
             // ---- LDS lookups: sRGB, BRDF LUT, irradiance -----------------------------------------------------------------------
             // table byte offsets straight from the packed texel: (c << 2) & 0x3FC, (c >> 6) & 0x3FC, (c >> 14) & 0x3FC
             const unsigned char* srgbB = reinterpret_cast<const unsigned char*>(srgb);
-            const F3 albedo = f3(*reinterpret_cast<const float*>(srgbB + ((gc << 2) & 0x3FCu)), *reinterpret_cast<const float*>(srgbB + ((gc >> 6) & 0x3FCu)),
-                                 *reinterpret_cast<const float*>(srgbB + ((gc >> 14) & 0x3FCu)));
-            float ba, bb;
+            const f2_t albxy = f2(*reinterpret_cast<const float*>(srgbB + ((gc << 2) & 0x3FCu)), *reinterpret_cast<const float*>(srgbB + ((gc >> 6) & 0x3FCu)));
+            const float albz = *reinterpret_cast<const float*>(srgbB + ((gc >> 14) & 0x3FCu));
+            f2_t bab; // (brdf.x, brdf.y)
             {
                 // bordered coordinates: x in [0.5, W + 0.5] (NdotV is saturated), y clamped likewise (roughness is not)
                 const float x = fmaf(NdotV, (float)kLutW, 0.5f);
                 const float y = __builtin_amdgcn_fmed3f(fmaf(roughness, (float)kLutH, 0.5f), 0.5f, (float)kLutH + 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
-                const float fx = x - i0, fy = y - j0;
-                const float2* t = lut + (uint32_t)fmaf(j0, (float)kLutE, i0);
-                const float2 t00 = t[0], t10 = t[1], t01 = t[kLutE], t11 = t[kLutE + 1];
-                const float wy0 = 1.0f - fy;
-                const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
-                ba = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
-                bb = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
-            }
-            F3 irradiance = f3(0.0f, 0.0f, 0.0f);
-            if (IRR_LDS) {
-                const float x = fmaf(uN, p.hot.irrNf, 0.5f), y = fmaf(vN, p.hot.irrNf, 0.5f);
-                const float i0 = floorf(x), j0 = floorf(y);
-                const float fx = x - i0, fy = y - j0;
-                // bilinear CELL (i0, j0) of the face (irrEf / irrEEf hold N + 1 and (N + 1)^2 when the table is in LDS): the polynomial
-                // a + b fx + c fy + d fx fy of each channel - one 64-byte entry, three ds_read_b128, ten VALU instructions (as
-                // texels: four reads, seventeen instructions; 74.3 -> 73.6 us)
-                const float4a* t = irrT + 4u * (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
-                const float4a cx = t[0], cy = t[1], cz = t[2];
-                const float fxy = fx * fy;
-                irradiance.x = fmaf(cx.w, fxy, fmaf(cx.z, fy, fmaf(cx.y, fx, cx.x)));
-                irradiance.y = fmaf(cy.w, fxy, fmaf(cy.z, fy, fmaf(cy.y, fx, cy.x)));
-                irradiance.z = fmaf(cz.w, fxy, fmaf(cz.z, fy, fmaf(cz.y, fx, cz.x)));
-            }
-            // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) ----------------------------------------
-            const F3 F0 = mix(f3(spec0, spec0, spec0), albedo, metallic);
-            float scs = 0.0f, p5 = 0.0f;
-            if (wave_direct) { // a wave without a lit pixel has direct = 0 whatever D, G and F are
-                F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
-                const float hr = rsq(dot(Hv, Hv));
-                const float NdotH = sat(dot(N, Hv) * hr);
-                const float VdotH = dot(V, Hv) * hr; // = (1 + V.L)/|V + L| in [0,1]: saturate is the identity up to rounding
-                const float alpha = roughness * roughness;
-                const float alpha2 = alpha * alpha;
-                const float denom = fmaf(NdotH * NdotH, alpha2 - 1.0f, 1.0f);
-                const float D = alpha2 * rcp(fmaxf(3.14159265f * denom * denom, 1e-4f));
-                float k = roughness + 1.0f;
-                k = (k * k) * 0.125f;
-                const float omk = 1.0f - k;
-                // G / max(4 NdotL NdotV, 1e-4) * D, one reciprocal for the three denominators
-                const float gv = fmaf(NdotV, omk, k), gl = fmaf(NdotL, omk, k);
-                // max(4 x, 1e-4) = 4 max(x, 1e-4 / 4) exactly (power-of-two scaling)
-                const float nvl = NdotV * NdotL;
-                scs = (D * nvl) * rcp((gv * gl) * (4.0f * fmaxf(nvl, 1e-4f * 0.25f)));
-                const float om = 1.0f - VdotH;
-                const float om2 = om * om;
-                p5 = om2 * om2 * om;
-            }
-            float kdm = 1.0f - metallic;
-            // the math above is wanted BEFORE the first wait on a gather, not sunk behind it
-            asm volatile("" : "+v"(scs), "+v"(p5), "+v"(kdm), "+v"(ba), "+v"(bb), "+v"(irradiance.x), "+v"(irradiance.y), "+v"(irradiance.z));
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- shadow filter (its taps were issued last: their wait covers every gather) -------------------------------------
-            float shadow = 1.0f;
-            if (wave_lit) {
-                // PCF = 1 - 0.25 sum w (cmp > t) with separable weights (1-f, 1, f); then lerp(1, pcf, strength)
-                const float cb = cmp * 0x1p126f;
-                const float wx0 = 1.0f - sfx, wy0 = 1.0f - sfy;
-                const float r0 = fmaf(gt_step(cb, sa.z, negBig), sfx, fmaf(gt_step(cb, sa.x, negBig), wx0, gt_step(cb, sa.y, negBig)));
-                const float r1 = fmaf(gt_step(cb, sb.z, negBig), sfx, fmaf(gt_step(cb, sb.x, negBig), wx0, gt_step(cb, sb.y, negBig)));
-                const float r2 = fmaf(gt_step(cb, sc3.z, negBig), sfx, fmaf(gt_step(cb, sc3.x, negBig), wx0, gt_step(cb, sc3.y, negBig)));
-                shadow = fmaf(fmaf(sfy, r2, fmaf(wy0, r0, r1)), p.hot.shadowNegQuarterStrength, 1.0f);
-                if (__builtin_expect(__any(!fast), 0)) { // some pixel's footprint touches the border (or lies outside the map)
-                    const bool lit = xa >= -0.5f && ya >= -0.5f && xa <= kp->hot.shadowXmax && ya <= kp->hot.shadowYmax;
-                    if (!fast) {
-                        const float xa0 = floorf(xa), ya0 = floorf(ya);
-                        const float s = shadow_pcf_border_inline(p.hot.shadow, kp->hot.shadowWi, kp->hot.shadowHi, (int)xa0, (int)ya0, sfx, sfy, cmp);
-                        shadow = mix(1.0f, s, kp->hot.shadowStrength);
-                    }
-                    if (!lit) shadow = 1.0f;
+                const f2_t fxy = (PK & 16) ? f2(x, y) - f2(i0, j0) : f2(x - i0, y - j0);
+                const f2_t* t = reinterpret_cast<const f2_t*>(lut) + (uint32_t)fmaf(j0, (float)kLutE, i0);
+                const f2_t t00 = t[0], t10 = t[1], t01 = t[kLutE], t11 = t[kLutE + 1];
+                if (PK & 2) {
+                    // w11 = fx fy, (w10, w01) = (fx, fy) - w11, w00 = (1 - fx) - w01; each texel is the (brdf.x, brdf.y) pair
+                    const float w11 = fxy.x * fxy.y;
+                    const f2_t w1001 = fxy - splat(w11);
+                    const float w00 = (1.0f - fxy.x) - w1001.y;
+                    bab = pk_fma(t11, splat(w11), pk_fma(t01, w1001.yy, pk_fma(t10, w1001.xx, t00 * splat(w00))));
+                } else {
+                    const float fx = fxy.x, fy = fxy.y;
+                    const float wy0 = 1.0f - fy;
+                    const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
+                    bab = f2(fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x))), fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y))));
                 }
             }
+            f2_t irrxy = f2(0.0f, 0.0f);
+            float irrz = 0.0f;
+            if (IRR_LDS) {
+                const f2_t xy = (PK & 16) ? pk_fma(uvN, splat(p.hot.irrNf), splat(0.5f)) : f2(fmaf(uvN.x, p.hot.irrNf, 0.5f), fmaf(uvN.y, p.hot.irrNf, 0.5f));
+                const float i0 = floorf(xy.x), j0 = floorf(xy.y);
+                const f2_t fxy2 = (PK & 16) ? xy - f2(i0, j0) : f2(xy.x - i0, xy.y - j0);
+                const float fx = fxy2.x, fy = fxy2.y;
+                // bilinear CELL (i0, j0) of the face (irrEf / irrEEf hold N + 1 and (N + 1)^2 when the table is in LDS): the polynomial
+                // a + b fx + c fy + d fx fy of each channel - one 64-byte entry, three ds_read_b128, laid out as
+                // (a.x a.y b.x b.y | c.x c.y d.x d.y | a.z b.z c.z d.z): x and y are evaluated as a packed pair
+                const float4a* t = irrT + 4u * (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
+                const float4a c0 = t[0], c1 = t[1], c2 = t[2];
+                const float fxy = fx * fy;
+                if (PK & 2) irrxy = pk_fma(f2(c1.z, c1.w), splat(fxy), pk_fma(f2(c1.x, c1.y), splat(fy), pk_fma(f2(c0.z, c0.w), splat(fx), f2(c0.x, c0.y))));
+                else irrxy = f2(fmaf(c1.z, fxy, fmaf(c1.x, fy, fmaf(c0.z, fx, c0.x))), fmaf(c1.w, fxy, fmaf(c1.y, fy, fmaf(c0.w, fx, c0.y))));
+                irrz = fmaf(c2.w, fxy, fmaf(c2.z, fy, fmaf(c2.y, fx, c2.x)));
+            }
+            // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) ----------------------------------------
+            float kdm = 1.0f - metallic;
+            f2_t F0xy;
+            float F0z;
+            if (PK & 1) { // lerp(spec0, albedo, metallic) = albedo * metallic + spec0 * (1 - metallic)
+                const float s0k = spec0 * kdm;
+                F0xy = (PK & 4) ? pk_fma(albxy, splat(metallic), splat(s0k)) : f2(fmaf(albxy.x, metallic, s0k), fmaf(albxy.y, metallic, s0k));
+                F0z = fmaf(albz, metallic, s0k);
+            } else {
+                F0xy = f2(mix(spec0, albxy.x, metallic), mix(spec0, albxy.y, metallic));
+                F0z = mix(spec0, albz, metallic);
+            }
+            // the math above is wanted BEFORE the first wait on a gather, not sunk behind it
+            asm volatile("" : "+v"(scs), "+v"(p5), "+v"(kdm), "+v"(bab), "+v"(irrxy), "+v"(irrz));
+            __builtin_amdgcn_sched_barrier(0);
             need(p0a, p0b, p1a, p1b);
             if (!IRR_LDS) need(pia, pib, pia, pib);
             __builtin_amdgcn_sched_barrier(0);
@@ -1119,15 +1195,26 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             UR_PREFETCH_POINT();
             __builtin_amdgcn_sched_barrier(0);
             // ---- filter, combine ---------------------------------------------------------------------------------------------------
-            const float sh_l = shadow * NdotL;
-            F3 prefiltered;
+            f2_t prexy;
+            float prez;
             {
                 // The 24 mixed-precision FMAs below cannot share an issue slot with anything (tools/microbench/valu_rate4.hip):
                 // a weight computed BETWEEN two of them costs a slot of its own, computed next to another weight half of one.
                 const float s0 = 1.0f - fl;
-                float a1 = fy0 * s0, a0 = s0 - a1, b1 = fy1 * fl, b0 = fl - b1;
-                float a10 = a0 * fx0, a00 = a0 - a10, a11 = a1 * fx0, a01 = a1 - a11;
-                float b10 = b0 * fx1, b00 = b0 - b10, b11 = b1 * fx1, b01 = b1 - b11;
+                float a00, a10, a01, a11, b00, b10, b01, b11;
+                if (PK & 16) {
+                    // per mip: P = (w_y0, w_y1) scaled by the mip's weight, Q = P * fx = (w10, w11), P - Q = (w00, w01)
+                    const float a1 = f0.y * s0, b1 = f1.y * fl;
+                    const f2_t Pa = f2(s0 - a1, a1), Pb = f2(fl - b1, b1);
+                    const f2_t Qa = Pa * f0.xx, Qb = Pb * f1.xx;
+                    const f2_t Sa = Pa - Qa, Sb = Pb - Qb;
+                    a00 = Sa.x; a01 = Sa.y; a10 = Qa.x; a11 = Qa.y; b00 = Sb.x; b01 = Sb.y; b10 = Qb.x; b11 = Qb.y;
+                } else {
+                    const float fx0 = f0.x, fy0 = f0.y, fx1 = f1.x, fy1 = f1.y;
+                    float a1 = fy0 * s0, a0 = s0 - a1, b1 = fy1 * fl, b0 = fl - b1;
+                    a10 = a0 * fx0; a00 = a0 - a10; a11 = a1 * fx0; a01 = a1 - a11;
+                    b10 = b0 * fx1; b00 = b0 - b10; b11 = b1 * fx1; b01 = b1 - b11;
+                }
                 asm volatile("" : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11));
                 float x, y, z;
                 x = mul_lo(p0a.x, a00); y = mul_hi(p0a.x, a00); z = mul_lo(p0a.y, a00);
@@ -1138,31 +1225,80 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 x = mix_lo(x, p1a.z, b10); y = mix_hi(y, p1a.z, b10); z = mix_lo(z, p1a.w, b10);
                 x = mix_lo(x, p1b.x, b01); y = mix_hi(y, p1b.x, b01); z = mix_lo(z, p1b.y, b01);
                 x = mix_lo(x, p1b.z, b11); y = mix_hi(y, p1b.z, b11); z = mix_lo(z, p1b.w, b11);
-                prefiltered = f3(x, y, z);
+                prexy = f2(x, y); prez = z;
                 if (!IRR_LDS) {
                     CubeTaps t;
+                    F3 irradiance;
                     t.r0 = uint4u{pia.x, pia.y, pia.z, pia.w}; t.r1 = uint4u{pib.x, pib.y, pib.z, pib.w}; t.fx = fxi; t.fy = fyi;
                     cube_taps_filter<false>(irradiance, t, 1.0f); // irrFrac == 0 in this kernel
+                    irrxy = f2(irradiance.x, irradiance.y); irrz = irradiance.z;
                 }
             }
             // ambient = irradiance * (1 - metallic) * albedo + prefiltered * (F0 * brdf.x + brdf.y)
-            const F3 A = f3(kdm * albedo.x, kdm * albedo.y, kdm * albedo.z); // diffuse weight, also irradiance's
-            F3 color = f3(fmaf(irradiance.x, A.x, prefiltered.x * fmaf(F0.x, ba, bb)), fmaf(irradiance.y, A.y, prefiltered.y * fmaf(F0.y, ba, bb)),
-                          fmaf(irradiance.z, A.z, prefiltered.z * fmaf(F0.z, ba, bb)));
+            f2_t Axy, colxy;
+            float Az, colz;
+            if (PK & 4) {
+                Axy = albxy * splat(kdm); // diffuse weight, also irradiance's
+                colxy = pk_fma(irrxy, Axy, prexy * pk_fma(F0xy, bab.xx, bab.yy));
+            } else {
+                Axy = f2(kdm * albxy.x, kdm * albxy.y);
+                colxy = f2(fmaf(irrxy.x, Axy.x, prexy.x * fmaf(F0xy.x, bab.x, bab.y)), fmaf(irrxy.y, Axy.y, prexy.y * fmaf(F0xy.y, bab.x, bab.y)));
+            }
+            Az = kdm * albz;
+            colz = fmaf(irrz, Az, prez * fmaf(F0z, bab.x, bab.y));
             if (wave_direct) { // + ((1 - F) A + F sc) * light * shadow * N.L, which is zero in every lane of an unlit wave
-#define UR_CHANNEL(ch, i)                                                                                     \
+                // ---- shadow filter first (the same uniform region: the explicit vmcnt(0) at the prefetch point has retired its taps) ----
+                float shadow = 1.0f;
+                if (SHADOWS) {
+                    // PCF = 1 - 0.25 sum w (cmp > t) with separable weights (1-f, 1, f); then lerp(1, pcf, strength)
+                    const float sfx = sf.x, sfy = sf.y;
+                    const float cb = cmp * 0x1p126f;
+                    const float wx0 = 1.0f - sfx, wy0 = 1.0f - sfy;
+                    const float r0 = fmaf(gt_step(cb, sa.z, negBig), sfx, fmaf(gt_step(cb, sa.x, negBig), wx0, gt_step(cb, sa.y, negBig)));
+                    const float r1 = fmaf(gt_step(cb, sb.z, negBig), sfx, fmaf(gt_step(cb, sb.x, negBig), wx0, gt_step(cb, sb.y, negBig)));
+                    const float r2 = fmaf(gt_step(cb, sc3.z, negBig), sfx, fmaf(gt_step(cb, sc3.x, negBig), wx0, gt_step(cb, sc3.y, negBig)));
+                    shadow = fmaf(fmaf(sfy, r2, fmaf(wy0, r0, r1)), p.hot.shadowNegQuarterStrength, 1.0f);
+                    if (__builtin_expect(any_slow != 0u, 0)) { // some pixel's footprint touches the border (or lies outside the map)
+                        const float xa = xya.x, ya = xya.y;
+                        const bool lit = xa >= -0.5f && ya >= -0.5f && xa <= kp->hot.shadowXmax && ya <= kp->hot.shadowYmax;
+                        const float xa0 = floorf(xa), ya0 = floorf(ya);
+                        if (!(__builtin_amdgcn_fmed3f(xa0, 0.0f, kp->hot.shadowWm3) == xa0 && __builtin_amdgcn_fmed3f(ya0, 0.0f, kp->hot.shadowHm3) == ya0)) {
+                            const float s = shadow_pcf_border_inline(p.hot.shadow, kp->hot.shadowWi, kp->hot.shadowHi, (int)xa0, (int)ya0, sfx, sfy, cmp);
+                            shadow = mix(1.0f, s, kp->hot.shadowStrength);
+                        }
+                        if (!lit) shadow = 1.0f;
+                    }
+                }
+                const float sh_l = shadow * NdotL;
+                if (PK & 4) {
+                    // F = F0 + (1 - F0) p5 = F0 (1 - p5) + p5; direct = A + F (sc - A)
+                    const float omp5 = 1.0f - p5;
+                    const f2_t Fxy = pk_fma(F0xy, splat(omp5), splat(p5));
+                    const float Fz = fmaf(F0z, omp5, p5);
+                    const f2_t dxy = pk_fma(Fxy, splat(scs) - Axy, Axy);
+                    const float dz = fmaf(Fz, scs - Az, Az);
+                    colxy = pk_fma(dxy, lightRGBxy * splat(sh_l), colxy);
+                    colz = fmaf(dz, lightRGB[2] * sh_l, colz);
+                } else {
+#define UR_CHANNEL(F0c, Ac, colc, i)                                                                          \
     {                                                                                                         \
-        const float F = fmaf(1.0f - F0.ch, p5, F0.ch);                                                        \
-        const float direct = fmaf(F, scs - A.ch, A.ch);                                                       \
-        color.ch = fmaf(direct, lightRGB[i] * sh_l, color.ch);                                                \
+        const float F = fmaf(1.0f - F0c, p5, F0c);                                                            \
+        const float direct = fmaf(F, scs - Ac, Ac);                                                           \
+        colc = fmaf(direct, lightRGB[i] * sh_l, colc);                                                        \
     }
-                UR_CHANNEL(x, 0)
-                UR_CHANNEL(y, 1)
-                UR_CHANNEL(z, 2)
+                    UR_CHANNEL(F0xy.x, Axy.x, colxy.x, 0)
+                    UR_CHANNEL(F0xy.y, Axy.y, colxy.y, 1)
+                    UR_CHANNEL(F0z, Az, colz, 2)
 #undef UR_CHANNEL
+                }
             }
             if (!sky) {
-                out = f3(h2f_lo(gd.x) + color.x, h2f_hi(gd.x) + color.y, h2f_lo(gd.y) + color.z);
+                if (PK & 4) {
+                    const f2_t o = f2(h2f_lo(gd.x), h2f_hi(gd.x)) + colxy;
+                    out = f3(o.x, o.y, h2f_lo(gd.y) + colz);
+                } else {
+                    out = f3(h2f_lo(gd.x) + colxy.x, h2f_hi(gd.x) + colxy.y, h2f_lo(gd.y) + colz);
+                }
                 outw = h2f_hi(gd.y) + 1.0f;
             }
         } else {
@@ -1179,7 +1315,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             store_hdr(p.hot.hdr, ((ty * 4u) * p.hot.W + tx * 16u) * 8u + laneHdr, ob.x, ob.y);
         }
         if (!more1) break;
-        tile = tile1; tile1 = tile2; // tile2 stays 0xFFFFFFFF when nothing was left to claim
+        tile = tile1; tile1 = tile2; // (0xFFFFFFFF when nothing was left to claim)
         tx = tx1; ty = ty1; tx1 = tx2; ty1 = ty2;
         parity ^= 1u;
     }
