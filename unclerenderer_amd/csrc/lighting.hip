@@ -25,10 +25,6 @@
 
 #include <hip/hip_ext.h>
 
-#ifndef UR_PK
-#define UR_PK 1 // TEMPORARY (round-3 experiment): which groups of the loop use the dieted / packed forms
-#endif
-
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
@@ -148,13 +144,13 @@ __device__ __forceinline__ float3u ld<float3u>(const void* base, uint32_t byte_o
     return {v.x, v.y, v.z};
 }
 
-// Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of one operation on an even-aligned register
-// pair; a scalar operand is broadcast through op_sel at no cost). A packed instruction holds the SIMD's issue port ~5 cycles
-// against ~3.25 for a plain one (tools/microbench/valu_rate.hip): 2.5 per operation where BOTH halves are wanted.
+// The x, y halves of a vector as a pair. Packed fp32 arithmetic on such pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 through
+// the vector type: hipcc pairs the registers and broadcasts scalar operands through op_sel without a move) was built for every
+// per-channel chain of the loop in round 3 and measured: 100 plain instructions became 46 packed ones, no scratch, and the
+// launch took the same time (72.0 against 72.0-72.3 us for the five groups added one at a time, profiles/r03_lighting_diet.txt):
+// in this loop a packed instruction costs the issue port what its two halves would. The pairs below are plain containers.
 typedef float f2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2_t f2(float x, float y) { return f2_t{x, y}; }
-__device__ __forceinline__ f2_t splat(float x) { return f2_t{x, x}; }
-__device__ __forceinline__ f2_t pk_fma(f2_t a, f2_t b, f2_t c) { return __builtin_elementwise_fma(a, b, c); }
 
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { return {x, y, z}; }
@@ -847,10 +843,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     for (int k = 0; k < 3; ++k) {
         WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); shT[k] = vreg(p.hot.shT[k]); lightRGB[k] = vreg(p.hot.lightRGB[k]);
     }
-    // the x, y halves of the same constants as packed pairs (the same registers: a pair is two neighbouring VGPRs)
-    constexpr int PK = UR_PK;
-    const f2_t Rxy[3] = {f2(R[0], R[1]), f2(R[3], R[4]), f2(R[6], R[7])};
-    const f2_t WCxy = f2(WC[0], WC[1]), shCxy = f2(shC[0], shC[1]), shTxy = f2(shT[0], shT[1]), lightRGBxy = f2(lightRGB[0], lightRGB[1]);
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
         if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
@@ -994,32 +986,26 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const float nr = rsq(fmaf(nz, nz, fmaf(ny, ny, nx * nx))); // normalize(0) = NaN, as in the reference
             f2_t Nxy;
             float Nz;
-            if (PK & 8) {
-                Nxy = pk_fma(splat(nz), Rxy[2], pk_fma(splat(ny), Rxy[1], splat(nx) * Rxy[0])) * splat(nr);
-                Nz = fmaf(nz, R[8], fmaf(ny, R[5], nx * R[2])) * nr;
-            } else {
-                const F3 N = rot(f3(nx * nr, ny * nr, nz * nr), R);
-                Nxy = f2(N.x, N.y); Nz = N.z;
-            }
+            const F3 N = rot(f3(nx * nr, ny * nr, nz * nr), R);
+            Nxy = f2(N.x, N.y); Nz = N.z;
             const float viewZ = -wv;
             const float spec0 = h2f_lo(gb.x), metallic = h2f_hi(gb.x), roughness = h2f_lo(gb.y);
             const F3 L = f3(p.hot.Lw[0], p.hot.Lw[1], p.hot.Lw[2]);
             const float NdotLraw = fmaf(Nz, L.z, fmaf(Nxy.y, L.y, Nxy.x * L.x));
             const float NdotL = sat(NdotLraw);
             f2_t Wxy;
-            if (PK & 8) Wxy = pk_fma(splat(ndcx), f2(p.hot.WA[0], p.hot.WA[1]), pk_fma(splat(ndcy), f2(p.hot.WB[0], p.hot.WB[1]), WCxy));
-            else Wxy = f2(fmaf(ndcx, p.hot.WA[0], fmaf(ndcy, p.hot.WB[0], WC[0])), fmaf(ndcx, p.hot.WA[1], fmaf(ndcy, p.hot.WB[1], WC[1])));
+            Wxy = f2(fmaf(ndcx, p.hot.WA[0], fmaf(ndcy, p.hot.WB[0], WC[0])), fmaf(ndcx, p.hot.WA[1], fmaf(ndcy, p.hot.WB[1], WC[1])));
             const float Wz = fmaf(ndcx, p.hot.WA[2], fmaf(ndcy, p.hot.WB[2], WC[2])); // (ra, rb, 1) * ViewInverse3x3
             // V = normalize(-viewPos) = -sign(viewZ) Wd / |Wd|; sign(-viewZ) is the stored sign of A.w
             const float vs = __builtin_copysignf(rsq(fmaf(Wz, Wz, fmaf(Wxy.y, Wxy.y, Wxy.x * Wxy.x))), wv);
-            const f2_t Vxy = (PK & 8) ? Wxy * splat(vs) : f2(Wxy.x * vs, Wxy.y * vs);
+            const f2_t Vxy = f2(Wxy.x * vs, Wxy.y * vs);
             const float Vz = Wz * vs;
             const float NdotVraw = fmaf(Nz, Vz, fmaf(Nxy.y, Vxy.y, Nxy.x * Vxy.x));
             const float NdotV = sat(NdotVraw);
             // ---- global gathers: the two prefiltered mips (bordered cube, addresses in fp32: every integer multiply would hold
             //      the issue port), then the shadow block ------------------------------------------------------------------------
             const float t2 = 2.0f * NdotVraw;
-            const f2_t Rxyw = (PK & 8) ? pk_fma(splat(t2), Nxy, -Vxy) : f2(fmaf(t2, Nxy.x, -Vxy.x), fmaf(t2, Nxy.y, -Vxy.y));
+            const f2_t Rxyw = f2(fmaf(t2, Nxy.x, -Vxy.x), fmaf(t2, Nxy.y, -Vxy.y));
             const F3 Rw = f3(Rxyw.x, Rxyw.y, fmaf(t2, Nz, -Vz));
             const float lvl = __builtin_amdgcn_fmed3f(roughness * p.hot.maxMip, 0.0f, p.hot.envMaxLevel);
             const float fl = __builtin_amdgcn_fractf(lvl);
@@ -1029,23 +1015,22 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const float faceR = __builtin_amdgcn_cubeid(Rw.x, Rw.y, Rw.z);
             const float invR = rcp(fabsf(__builtin_amdgcn_cubema(Rw.x, Rw.y, Rw.z)));
             f2_t uvR;
-            if (PK & 16) uvR = pk_fma(f2(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), __builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z)), splat(invR), splat(0.5f));
-            else uvR = f2(fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f), fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f));
+            uvR = f2(fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f), fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f));
             const void* env = p.hot.env;
             u32x4_t p0a, p0b, p1a, p1b;
             f2_t f0, f1; // (fx, fy) of the two mips
             {
-                const f2_t xy = (PK & 16) ? pk_fma(uvR, splat(e0.x), splat(0.5f)) : f2(fmaf(uvR.x, e0.x, 0.5f), fmaf(uvR.y, e0.x, 0.5f)); // bordered coordinates in [0.5, N + 0.5]
+                const f2_t xy = f2(fmaf(uvR.x, e0.x, 0.5f), fmaf(uvR.y, e0.x, 0.5f)); // bordered coordinates in [0.5, N + 0.5]
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
-                f0 = (PK & 16) ? xy - f2(i0, j0) : f2(xy.x - i0, xy.y - j0);
+                f0 = f2(xy.x - i0, xy.y - j0);
                 const uint32_t o = (uint32_t)(fmaf(faceR, e0.z, fmaf(j0, e0.y, i0)) + e0.w) * 8u;
                 p0a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 p0b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB0));
             }
             {
-                const f2_t xy = (PK & 16) ? pk_fma(uvR, splat(e1.x), splat(0.5f)) : f2(fmaf(uvR.x, e1.x, 0.5f), fmaf(uvR.y, e1.x, 0.5f));
+                const f2_t xy = f2(fmaf(uvR.x, e1.x, 0.5f), fmaf(uvR.y, e1.x, 0.5f));
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
-                f1 = (PK & 16) ? xy - f2(i0, j0) : f2(xy.x - i0, xy.y - j0);
+                f1 = f2(xy.x - i0, xy.y - j0);
                 const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 8u;
                 p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
                 p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB1));
@@ -1053,8 +1038,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const float faceN = __builtin_amdgcn_cubeid(Nxy.x, Nxy.y, Nz);
             const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nxy.x, Nxy.y, Nz)));
             f2_t uvN;
-            if (PK & 16) uvN = pk_fma(f2(__builtin_amdgcn_cubesc(Nxy.x, Nxy.y, Nz), __builtin_amdgcn_cubetc(Nxy.x, Nxy.y, Nz)), splat(invN), splat(0.5f));
-            else uvN = f2(fmaf(__builtin_amdgcn_cubesc(Nxy.x, Nxy.y, Nz), invN, 0.5f), fmaf(__builtin_amdgcn_cubetc(Nxy.x, Nxy.y, Nz), invN, 0.5f));
+            uvN = f2(fmaf(__builtin_amdgcn_cubesc(Nxy.x, Nxy.y, Nz), invN, 0.5f), fmaf(__builtin_amdgcn_cubetc(Nxy.x, Nxy.y, Nz), invN, 0.5f));
             u32x4_t pia = {0, 0, 0, 0}, pib = {0, 0, 0, 0};
             float fxi = 0.0f, fyi = 0.0f;
             if (!IRR_LDS) {
@@ -1078,11 +1062,10 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             if (wave_direct) {
                 if (SHADOWS) {
                     // orthographic light: (su * W - 0.5, sv * H - 0.5, z - bias) = viewZ * (affine in ndc) + constant
-                    if (PK & 16) xya = pk_fma(splat(viewZ), pk_fma(splat(ndcx), f2(p.hot.shA[0], p.hot.shA[1]), pk_fma(splat(ndcy), f2(p.hot.shB[0], p.hot.shB[1]), shCxy)), shTxy);
-                    else xya = f2(fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), shT[0]), fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), shT[1]));
+                    xya = f2(fmaf(viewZ, fmaf(ndcx, p.hot.shA[0], fmaf(ndcy, p.hot.shB[0], shC[0])), shT[0]), fmaf(viewZ, fmaf(ndcx, p.hot.shA[1], fmaf(ndcy, p.hot.shB[1], shC[1])), shT[1]));
                     cmp = fmaf(viewZ, fmaf(ndcx, p.hot.shA[2], fmaf(ndcy, p.hot.shB[2], shC[2])), shT[2]);
                     const float xa0 = floorf(xya.x), ya0 = floorf(xya.y);
-                    sf = (PK & 16) ? xya - f2(xa0, ya0) : f2(xya.x - xa0, xya.y - ya0);
+                    sf = f2(xya.x - xa0, xya.y - ya0);
                     // 3x3 block origin clamped into the map (always a valid address); unclamped <=> no tap touches the border
                     const float ic = __builtin_amdgcn_fmed3f(xa0, 0.0f, p.hot.shadowWm3), jc = __builtin_amdgcn_fmed3f(ya0, 0.0f, p.hot.shadowHm3);
                     any_slow = flag_any(ic != xa0) | flag_any(jc != ya0); // (each ballot straight off its comparison)
@@ -1093,19 +1076,11 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                     sc3 = *reinterpret_cast<const UR_GLOBAL f32x3_a4*>((const UR_GLOBAL char*)smap + o2);
                 }
                 float NdotH, om;
-                if (PK & 1) {
-                    // V and L are unit vectors: |V + L|^2 = 2 + 2 V.L, N.(V + L) = N.V + N.L, V.(V + L) = 1 + V.L
-                    const float VL = fmaf(Vz, L.z, fmaf(Vxy.y, L.y, Vxy.x * L.x));
-                    const float hr = rsq(fmaf(VL, 2.0f, 2.0f));
-                    NdotH = sat((NdotVraw + NdotLraw) * hr);
-                    om = fmaf(-VL, hr, 1.0f - hr); // 1 - VdotH, VdotH = (1 + V.L) / |V + L| in [0,1]: saturate is the identity up to rounding
-                } else {
-                    const F3 V = f3(Vxy.x, Vxy.y, Vz), N = f3(Nxy.x, Nxy.y, Nz);
-                    F3 Hv = f3(V.x + L.x, V.y + L.y, V.z + L.z);
-                    const float hr = rsq(dot(Hv, Hv));
-                    NdotH = sat(dot(N, Hv) * hr);
-                    om = 1.0f - dot(V, Hv) * hr;
-                }
+                // V and L are unit vectors: |V + L|^2 = 2 + 2 V.L, N.(V + L) = N.V + N.L, V.(V + L) = 1 + V.L
+                const float VL = fmaf(Vz, L.z, fmaf(Vxy.y, L.y, Vxy.x * L.x));
+                const float hr = rsq(fmaf(VL, 2.0f, 2.0f));
+                NdotH = sat((NdotVraw + NdotLraw) * hr);
+                om = fmaf(-VL, hr, 1.0f - hr); // 1 - VdotH, VdotH = (1 + V.L) / |V + L| in [0,1]: saturate is the identity up to rounding
                 const float alpha = roughness * roughness;
                 const float alpha2 = alpha * alpha;
                 const float denom = fmaf(NdotH * NdotH, alpha2 - 1.0f, 1.0f);
@@ -1115,14 +1090,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const float gv = fmaf(NdotV, omk, k), gl = fmaf(NdotL, omk, k);
                 // max(4 x, 1e-4) = 4 max(x, 1e-4 / 4) exactly (power-of-two scaling)
                 const float nvl = NdotV * NdotL;
-                if (PK & 1) {
-                    // D G / max(4 NdotL NdotV, 1e-4) with ONE reciprocal: every factor of the denominator is >= 1e-4 and <= ~40, their
-                    // product stays far inside the fp32 range
-                    scs = (alpha2 * nvl) * rcp((fmaxf(3.14159265f * denom * denom, 1e-4f) * (gv * gl)) * (4.0f * fmaxf(nvl, 1e-4f * 0.25f)));
-                } else {
-                    const float D = alpha2 * rcp(fmaxf(3.14159265f * denom * denom, 1e-4f));
-                    scs = (D * nvl) * rcp((gv * gl) * (4.0f * fmaxf(nvl, 1e-4f * 0.25f)));
-                }
+                // D G / max(4 NdotL NdotV, 1e-4) with ONE reciprocal: every factor of the denominator is >= 1e-4 and <= ~40, their
+                // product stays far inside the fp32 range
+                scs = (alpha2 * nvl) * rcp((fmaxf(3.14159265f * denom * denom, 1e-4f) * (gv * gl)) * (4.0f * fmaxf(nvl, 1e-4f * 0.25f)));
                 const float om2 = om * om;
                 p5 = om2 * om2 * om;
             }
@@ -1137,28 +1107,20 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const float x = fmaf(NdotV, (float)kLutW, 0.5f);
                 const float y = __builtin_amdgcn_fmed3f(fmaf(roughness, (float)kLutH, 0.5f), 0.5f, (float)kLutH + 0.5f);
                 const float i0 = floorf(x), j0 = floorf(y);
-                const f2_t fxy = (PK & 16) ? f2(x, y) - f2(i0, j0) : f2(x - i0, y - j0);
+                const f2_t fxy = f2(x - i0, y - j0);
                 const f2_t* t = reinterpret_cast<const f2_t*>(lut) + (uint32_t)fmaf(j0, (float)kLutE, i0);
                 const f2_t t00 = t[0], t10 = t[1], t01 = t[kLutE], t11 = t[kLutE + 1];
-                if (PK & 2) {
-                    // w11 = fx fy, (w10, w01) = (fx, fy) - w11, w00 = (1 - fx) - w01; each texel is the (brdf.x, brdf.y) pair
-                    const float w11 = fxy.x * fxy.y;
-                    const f2_t w1001 = fxy - splat(w11);
-                    const float w00 = (1.0f - fxy.x) - w1001.y;
-                    bab = pk_fma(t11, splat(w11), pk_fma(t01, w1001.yy, pk_fma(t10, w1001.xx, t00 * splat(w00))));
-                } else {
-                    const float fx = fxy.x, fy = fxy.y;
-                    const float wy0 = 1.0f - fy;
-                    const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
-                    bab = f2(fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x))), fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y))));
-                }
+                const float fx = fxy.x, fy = fxy.y;
+                const float wy0 = 1.0f - fy;
+                const float w10 = wy0 * fx, w00 = wy0 - w10, w11 = fy * fx, w01 = fy - w11;
+                bab = f2(fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x))), fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y))));
             }
             f2_t irrxy = f2(0.0f, 0.0f);
             float irrz = 0.0f;
             if (IRR_LDS) {
-                const f2_t xy = (PK & 16) ? pk_fma(uvN, splat(p.hot.irrNf), splat(0.5f)) : f2(fmaf(uvN.x, p.hot.irrNf, 0.5f), fmaf(uvN.y, p.hot.irrNf, 0.5f));
+                const f2_t xy = f2(fmaf(uvN.x, p.hot.irrNf, 0.5f), fmaf(uvN.y, p.hot.irrNf, 0.5f));
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
-                const f2_t fxy2 = (PK & 16) ? xy - f2(i0, j0) : f2(xy.x - i0, xy.y - j0);
+                const f2_t fxy2 = f2(xy.x - i0, xy.y - j0);
                 const float fx = fxy2.x, fy = fxy2.y;
                 // bilinear CELL (i0, j0) of the face (irrEf / irrEEf hold N + 1 and (N + 1)^2 when the table is in LDS): the polynomial
                 // a + b fx + c fy + d fx fy of each channel - one 64-byte entry, three ds_read_b128, laid out as
@@ -1166,22 +1128,17 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const float4a* t = irrT + 4u * (uint32_t)fmaf(faceN, p.hot.irrEEf, fmaf(j0, p.hot.irrEf, i0));
                 const float4a c0 = t[0], c1 = t[1], c2 = t[2];
                 const float fxy = fx * fy;
-                if (PK & 2) irrxy = pk_fma(f2(c1.z, c1.w), splat(fxy), pk_fma(f2(c1.x, c1.y), splat(fy), pk_fma(f2(c0.z, c0.w), splat(fx), f2(c0.x, c0.y))));
-                else irrxy = f2(fmaf(c1.z, fxy, fmaf(c1.x, fy, fmaf(c0.z, fx, c0.x))), fmaf(c1.w, fxy, fmaf(c1.y, fy, fmaf(c0.w, fx, c0.y))));
+                irrxy = f2(fmaf(c1.z, fxy, fmaf(c1.x, fy, fmaf(c0.z, fx, c0.x))), fmaf(c1.w, fxy, fmaf(c1.y, fy, fmaf(c0.w, fx, c0.y))));
                 irrz = fmaf(c2.w, fxy, fmaf(c2.z, fy, fmaf(c2.y, fx, c2.x)));
             }
             // ---- EvaluatePBR, PBRCommon.hlsl:24-48 (runs while the gathers are in flight) ----------------------------------------
             float kdm = 1.0f - metallic;
             f2_t F0xy;
             float F0z;
-            if (PK & 1) { // lerp(spec0, albedo, metallic) = albedo * metallic + spec0 * (1 - metallic)
-                const float s0k = spec0 * kdm;
-                F0xy = (PK & 4) ? pk_fma(albxy, splat(metallic), splat(s0k)) : f2(fmaf(albxy.x, metallic, s0k), fmaf(albxy.y, metallic, s0k));
-                F0z = fmaf(albz, metallic, s0k);
-            } else {
-                F0xy = f2(mix(spec0, albxy.x, metallic), mix(spec0, albxy.y, metallic));
-                F0z = mix(spec0, albz, metallic);
-            }
+            // lerp(spec0, albedo, metallic) = albedo * metallic + spec0 * (1 - metallic)
+            const float s0k = spec0 * kdm;
+            F0xy = f2(fmaf(albxy.x, metallic, s0k), fmaf(albxy.y, metallic, s0k));
+            F0z = fmaf(albz, metallic, s0k);
             // the math above is wanted BEFORE the first wait on a gather, not sunk behind it
             asm volatile("" : "+v"(scs), "+v"(p5), "+v"(kdm), "+v"(bab), "+v"(irrxy), "+v"(irrz));
             __builtin_amdgcn_sched_barrier(0);
@@ -1202,19 +1159,10 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 // a weight computed BETWEEN two of them costs a slot of its own, computed next to another weight half of one.
                 const float s0 = 1.0f - fl;
                 float a00, a10, a01, a11, b00, b10, b01, b11;
-                if (PK & 16) {
-                    // per mip: P = (w_y0, w_y1) scaled by the mip's weight, Q = P * fx = (w10, w11), P - Q = (w00, w01)
-                    const float a1 = f0.y * s0, b1 = f1.y * fl;
-                    const f2_t Pa = f2(s0 - a1, a1), Pb = f2(fl - b1, b1);
-                    const f2_t Qa = Pa * f0.xx, Qb = Pb * f1.xx;
-                    const f2_t Sa = Pa - Qa, Sb = Pb - Qb;
-                    a00 = Sa.x; a01 = Sa.y; a10 = Qa.x; a11 = Qa.y; b00 = Sb.x; b01 = Sb.y; b10 = Qb.x; b11 = Qb.y;
-                } else {
-                    const float fx0 = f0.x, fy0 = f0.y, fx1 = f1.x, fy1 = f1.y;
-                    float a1 = fy0 * s0, a0 = s0 - a1, b1 = fy1 * fl, b0 = fl - b1;
-                    a10 = a0 * fx0; a00 = a0 - a10; a11 = a1 * fx0; a01 = a1 - a11;
-                    b10 = b0 * fx1; b00 = b0 - b10; b11 = b1 * fx1; b01 = b1 - b11;
-                }
+                const float fx0 = f0.x, fy0 = f0.y, fx1 = f1.x, fy1 = f1.y;
+                float a1 = fy0 * s0, a0 = s0 - a1, b1 = fy1 * fl, b0 = fl - b1;
+                a10 = a0 * fx0; a00 = a0 - a10; a11 = a1 * fx0; a01 = a1 - a11;
+                b10 = b0 * fx1; b00 = b0 - b10; b11 = b1 * fx1; b01 = b1 - b11;
                 asm volatile("" : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11));
                 float x, y, z;
                 x = mul_lo(p0a.x, a00); y = mul_hi(p0a.x, a00); z = mul_lo(p0a.y, a00);
@@ -1237,13 +1185,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             // ambient = irradiance * (1 - metallic) * albedo + prefiltered * (F0 * brdf.x + brdf.y)
             f2_t Axy, colxy;
             float Az, colz;
-            if (PK & 4) {
-                Axy = albxy * splat(kdm); // diffuse weight, also irradiance's
-                colxy = pk_fma(irrxy, Axy, prexy * pk_fma(F0xy, bab.xx, bab.yy));
-            } else {
-                Axy = f2(kdm * albxy.x, kdm * albxy.y);
-                colxy = f2(fmaf(irrxy.x, Axy.x, prexy.x * fmaf(F0xy.x, bab.x, bab.y)), fmaf(irrxy.y, Axy.y, prexy.y * fmaf(F0xy.y, bab.x, bab.y)));
-            }
+            Axy = f2(kdm * albxy.x, kdm * albxy.y);
+            colxy = f2(fmaf(irrxy.x, Axy.x, prexy.x * fmaf(F0xy.x, bab.x, bab.y)), fmaf(irrxy.y, Axy.y, prexy.y * fmaf(F0xy.y, bab.x, bab.y)));
             Az = kdm * albz;
             colz = fmaf(irrz, Az, prez * fmaf(F0z, bab.x, bab.y));
             if (wave_direct) { // + ((1 - F) A + F sc) * light * shadow * N.L, which is zero in every lane of an unlit wave
@@ -1270,35 +1213,19 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                     }
                 }
                 const float sh_l = shadow * NdotL;
-                if (PK & 4) {
-                    // F = F0 + (1 - F0) p5 = F0 (1 - p5) + p5; direct = A + F (sc - A)
-                    const float omp5 = 1.0f - p5;
-                    const f2_t Fxy = pk_fma(F0xy, splat(omp5), splat(p5));
-                    const float Fz = fmaf(F0z, omp5, p5);
-                    const f2_t dxy = pk_fma(Fxy, splat(scs) - Axy, Axy);
-                    const float dz = fmaf(Fz, scs - Az, Az);
-                    colxy = pk_fma(dxy, lightRGBxy * splat(sh_l), colxy);
-                    colz = fmaf(dz, lightRGB[2] * sh_l, colz);
-                } else {
 #define UR_CHANNEL(F0c, Ac, colc, i)                                                                          \
-    {                                                                                                         \
-        const float F = fmaf(1.0f - F0c, p5, F0c);                                                            \
-        const float direct = fmaf(F, scs - Ac, Ac);                                                           \
-        colc = fmaf(direct, lightRGB[i] * sh_l, colc);                                                        \
-    }
-                    UR_CHANNEL(F0xy.x, Axy.x, colxy.x, 0)
-                    UR_CHANNEL(F0xy.y, Axy.y, colxy.y, 1)
-                    UR_CHANNEL(F0z, Az, colz, 2)
+{                                                                                                         \
+    const float F = fmaf(1.0f - F0c, p5, F0c);                                                            \
+    const float direct = fmaf(F, scs - Ac, Ac);                                                           \
+    colc = fmaf(direct, lightRGB[i] * sh_l, colc);                                                        \
+}
+                UR_CHANNEL(F0xy.x, Axy.x, colxy.x, 0)
+                UR_CHANNEL(F0xy.y, Axy.y, colxy.y, 1)
+                UR_CHANNEL(F0z, Az, colz, 2)
 #undef UR_CHANNEL
-                }
             }
             if (!sky) {
-                if (PK & 4) {
-                    const f2_t o = f2(h2f_lo(gd.x), h2f_hi(gd.x)) + colxy;
-                    out = f3(o.x, o.y, h2f_lo(gd.y) + colz);
-                } else {
-                    out = f3(h2f_lo(gd.x) + colxy.x, h2f_hi(gd.x) + colxy.y, h2f_lo(gd.y) + colz);
-                }
+                out = f3(h2f_lo(gd.x) + colxy.x, h2f_hi(gd.x) + colxy.y, h2f_lo(gd.y) + colz);
                 outw = h2f_hi(gd.y) + 1.0f;
             }
         } else {
