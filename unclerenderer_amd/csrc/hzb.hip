@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
         if (p.vec4_ok && sx + 3u < p.SW && sy + 3u < p.SH) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float4 q = *reinterpret_cast<const float4*>(p.src + (size_t)(sy + r) * p.SW + sx);
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                const f32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p.src + (size_t)(sy + r) * p.SW + sx)); // read once
                 s[r][0] = q.x; s[r][1] = q.y; s[r][2] = q.z; s[r][3] = q.w;
             }
         } else {
@@ -166,10 +167,10 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
         // the first launch also produces mip 4 when a tail launch follows: the tail then starts from 1/4 of the texels
         // (a single workgroup reads ~25 GB/s: 130 KB of mip 3 at 4K would be 5 us on its own)
         if (mip == 0 && mip_count > 4u && (uint64_t)mips[4].width * mips[4].height <= kTailTexels) n = 5u;
-        // What has to fit the tail's LDS is ITS first level, mip 5; its parent, mip 4, is read from global memory. At 8K
-        // that is 130 KB through one workgroup: a 9-us tail, 1.5 us SLOWER than a third launch when it runs on its own
-        // (41.6 against 40.0 us) - but free when it rides along with the Lighting launch.
-        else if (mip == 0 && ctx->defer_hzb_tail && mip_count > 5u && (uint64_t)mips[5].width * mips[5].height <= kTailTexels &&
+        // What has to fit the tail's LDS is ITS first level, mip 5; its parent, mip 4, is read from global memory: at 8K 130 KB
+        // through one workgroup. With 4-byte taps that was a 9-us tail (slower than a third launch); with the 16-byte loads of
+        // tail_first_level_vec it is two launches for every chain up to 8K.
+        else if (mip == 0 && mip_count > 5u && (uint64_t)mips[5].width * mips[5].height <= kTailTexels &&
                  mip_count - 5u <= kTailMaxLevels) n = 5u;
         HzbDispatch d{};
         if (mip == 0) {

@@ -58,6 +58,59 @@ __device__ __forceinline__ void tail_first_level(const P& p, float* bufA)
     }
 }
 
+// The same first level with 16-byte loads, for the shapes every 16:9 chain has there (parent width a multiple of four, parent
+// 16-byte aligned, no out-of-range tap: 2 W <= SW and 2 H <= SH): a thread takes the output PAIR (2j, 2j + 1) of a row from two
+// float4 loads (parent rows 2y and 2y + 1, columns 4j .. 4j + 3) — an eighth of the vector-memory instructions of the
+// tap-by-tap form (which at 8K made this single workgroup spend 9 us reading 130 KB: 1024 wave-instructions of 4 bytes per
+// lane), and TRIPS is chosen by the level's size instead of padding to the largest.
+typedef float tail_f32x4_t __attribute__((ext_vector_type(4)));
+
+template <uint32_t TRIPS, bool AGENT_LOADS, class P>
+__device__ __forceinline__ void tail_first_level_vec(const P& p, float* bufA)
+{
+    const uint32_t tid = threadIdx.x, W = p.W[0], W2 = W >> 1, npairs = W2 * p.H[0], SW = p.SW;
+    const uint32_t mg = W2 > 1u ? (uint32_t)((1ull << 32) / W2 + 1ull) : 0u; // i / W2 for i < 2^16 (exact: W2 <= 2^13)
+    tail_f32x4_t a[TRIPS], b[TRIPS];
+#pragma unroll
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t i = min(tid + k * 1024u, npairs - 1u); // clamped into the level: no branch separates the loads
+        const uint32_t y = W2 == 1u ? i : __umulhi(i, mg), j = i - y * W2;
+        const float* q = p.src + (size_t)(2u * y) * SW + 4u * j;
+        if (AGENT_LOADS) {
+            // written by other workgroups of the same launch (sc1 stores, drained, one arrival each): sc1 loads, served by L2
+            // (MI355X_MICROARCH.md, measured sc1 hand-offs, row 1: 16-byte loads are among the measured forms). An asm load is
+            // invisible to hipcc's wait bookkeeping and its destination counts as written at the statement: the destinations
+            // are the array elements themselves (no copy may sit between a load and the wait below) and nothing reads them
+            // before the wait statement that names them all.
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(a[k]) : "v"(q) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(b[k]) : "v"(q + SW) : "memory");
+        } else {
+            a[k] = *reinterpret_cast<const tail_f32x4_t*>(q);
+            b[k] = *reinterpret_cast<const tail_f32x4_t*>(q + SW);
+        }
+    }
+    if (AGENT_LOADS) {
+        if constexpr (TRIPS == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0])::"memory");
+        else if constexpr (TRIPS == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1])::"memory");
+        else if constexpr (TRIPS == 4)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3])::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]), "+v"(a[4]), "+v"(b[4]), "+v"(a[5]),
+                           "+v"(b[5]), "+v"(a[6]), "+v"(b[6]), "+v"(a[7]), "+v"(b[7])::"memory");
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < TRIPS; ++k) {
+        const uint32_t i = tid + k * 1024u;
+        if (i < npairs) {
+            const float v0 = hzb_min4(a[k].x, a[k].y, b[k].x, b[k].y), v1 = hzb_min4(a[k].z, a[k].w, b[k].z, b[k].w);
+            const uint32_t y = W2 == 1u ? i : __umulhi(i, mg), j = i - y * W2, o = y * W + 2u * j;
+            bufA[o] = v0; bufA[o + 1u] = v1;
+            p.dst[0][o] = v0; p.dst[0][o + 1u] = v1;
+        }
+    }
+}
+
 // 1024 threads; bufA holds kTailTexels floats, bufB half as many (LDS)
 template <bool AGENT_LOADS = false, class P> // P = HzbTail in any address space
 __device__ __forceinline__ void hzb_tail_run(const P& p, float* bufA, float* bufB)
@@ -65,7 +118,14 @@ __device__ __forceinline__ void hzb_tail_run(const P& p, float* bufA, float* buf
     const uint32_t tid = threadIdx.x;
     // first level of the tail: parent in global memory. Every load of the thread is issued before the first reduction:
     // one memory latency (8 or 16 texels x 4 taps).
-    if (p.W[0] * p.H[0] <= kTailTexels / 2u) tail_first_level<kTailTexels / 2048u, AGENT_LOADS>(p, bufA);
+    const uint32_t n0 = p.W[0] * p.H[0];
+    const bool vec = (p.SW & 3u) == 0u && (p.W[0] & 1u) == 0u && 2u * p.W[0] <= p.SW && 2u * p.H[0] <= p.SH &&
+                     (reinterpret_cast<uintptr_t>(p.src) & 15u) == 0u; // uniform
+    if (vec && n0 <= 2048u) tail_first_level_vec<1, AGENT_LOADS>(p, bufA);
+    else if (vec && n0 <= 4096u) tail_first_level_vec<2, AGENT_LOADS>(p, bufA);
+    else if (vec && n0 <= 8192u) tail_first_level_vec<4, AGENT_LOADS>(p, bufA);
+    else if (vec) tail_first_level_vec<8, AGENT_LOADS>(p, bufA);
+    else if (n0 <= kTailTexels / 2u) tail_first_level<kTailTexels / 2048u, AGENT_LOADS>(p, bufA);
     else tail_first_level<kTailTexels / 1024u, AGENT_LOADS>(p, bufA);
     __syncthreads();
     for (uint32_t l = 1; l < p.levels; ++l) { // uniform

@@ -1247,10 +1247,13 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         parity ^= 1u;
     }
 #undef UR_PREFETCH_POINT
-    if (p.timeline != nullptr) { // debug timeline: the workgroup's LAST wave to leave the loop stamps the exit (uniform branch)
+    // debug timeline: the workgroup's LAST wave to leave the loop stamps the exit (uniform branch). The pointer is re-read from the
+    // kernarg segment: kept in SGPRs across the loop it was two of the loop's eight spilled scalars.
+    unsigned long long* const tl = fresh_params()->timeline;
+    if (tl != nullptr) {
         uint32_t left = 0;
         if (lane == 0) left = __hip_atomic_fetch_add(work + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ur::timeline_exit(p.timeline, lane == 0 && left == WPB - 1u);
+        ur::timeline_exit(tl, lane == 0 && left == WPB - 1u);
     }
 }
 

@@ -30,14 +30,7 @@ namespace ur {
 
 int check_hzb_timeout(ur_ctx* ctx, const char* who)
 {
-    if (!ctx || !ctx->hzb_timed_out) return UR_OK;
-    if (ctx->hzb_timed_out[1] != 0u) { // the single-launch cull's wait for the workgroups in front of one (csrc/cull.hip)
-        ctx->hzb_timed_out[1] = 0u;
-        set_error("%s: a cull launch gave up waiting for a workgroup's visible count: its visible list is incomplete — cull again "
-                  "(reported once; the context is usable)", who);
-        return UR_ETIMEOUT;
-    }
-    if (*ctx->hzb_timed_out == 0u) return UR_OK;
+    if (!ctx || !ctx->hzb_timed_out || *ctx->hzb_timed_out == 0u) return UR_OK;
     *ctx->hzb_timed_out = 0u;
     (void)hipMemsetAsync(ctx->hzb_done, 0, 64, ctx->stream); // stragglers may have left any count behind
     set_error("%s: the tail of a Build HZB chain that rode a Lighting launch gave up waiting for its producers: the HZB's small levels are stale — "
@@ -169,8 +162,7 @@ ur_ctx* ur_create(int device, void* stream)
         }
         ctx->hzb_timed_out = static_cast<volatile uint32_t*>(host);
         ctx->hzb_timed_out_dev = static_cast<uint32_t*>(devp);
-        ctx->hzb_timed_out[0] = 0u;
-        ctx->hzb_timed_out[1] = 0u;
+        *ctx->hzb_timed_out = 0u;
     }
     if (ur_reserve(ctx, 1u << 20) != UR_OK) {
         ur_destroy(ctx);
@@ -189,8 +181,8 @@ void ur_destroy(ur_ctx* ctx)
     if (ctx->hzb_done) (void)hipFree(ctx->hzb_done);
     if (ctx->hzb_timed_out) (void)hipHostFree(const_cast<uint32_t*>(ctx->hzb_timed_out));
     if (ctx->srgb_table) (void)hipFree(ctx->srgb_table);
-    if (ctx->cull_aggregates) (void)hipFree(ctx->cull_aggregates);
-    if (ctx->cull_ticket) (void)hipFree(ctx->cull_ticket);
+    if (ctx->block_counts) (void)hipFree(ctx->block_counts);
+    if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
     delete ctx;
 }
 
@@ -240,32 +232,17 @@ int ur_reserve(ur_ctx* ctx, uint32_t max_instances)
 {
     if (!ctx) return UR_EINVAL;
     if (max_instances <= ctx->ws_instances) return UR_OK;
-    // one granule per workgroup of the single-launch cull: at most one per 256-instance chunk
-    const size_t groups = ((size_t)max_instances + 255u) / 256u;
     UR_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->cull_aggregates) (void)hipFree(ctx->cull_aggregates);
-    ctx->cull_aggregates = nullptr; ctx->cull_groups_cap = 0; ctx->ws_instances = 0;
-    // member granules [groups] + cluster granules [groups / 64 + 1]
-    const size_t granules = groups + groups / 64u + 1u;
-    if (hipMalloc(&ctx->cull_aggregates, granules * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->cull_aggregates, 0, granules * sizeof(unsigned long long)) != hipSuccess) {
+    if (ctx->block_counts) (void)hipFree(ctx->block_counts);
+    if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
+    ctx->block_counts = nullptr; ctx->wave_masks = nullptr; ctx->ws_instances = 0;
+    const size_t blocks = ((size_t)max_instances + 255u) / 256u;
+    if (hipMalloc(&ctx->block_counts, blocks * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&ctx->wave_masks, blocks * 4u * sizeof(uint64_t)) != hipSuccess) {
         set_error("ur_reserve: workspace allocation for %u instances failed", max_instances);
         return UR_ENOMEM;
     }
-    {
-        // words {ticket, finished, epoch} + (from word 16) one arrival counter per cluster of 64 workgroups
-        const uint32_t init[3] = {0u, 0u, 1u}; // (epoch 0 is what a fresh granule holds)
-        const size_t bytes = (16u + groups / 64u + 1u) * sizeof(uint32_t);
-        if (ctx->cull_ticket) (void)hipFree(ctx->cull_ticket);
-        ctx->cull_ticket = nullptr;
-        if (hipMalloc(&ctx->cull_ticket, bytes) != hipSuccess || hipMemset(ctx->cull_ticket, 0, bytes) != hipSuccess ||
-            hipMemcpy(ctx->cull_ticket, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
-            set_error("ur_reserve: ticket counter allocation failed");
-            return UR_ENOMEM;
-        }
-    }
-    ctx->cull_groups_cap = (uint32_t)groups;
-    ctx->ws_instances = (uint32_t)(groups * 256u);
+    ctx->ws_instances = (uint32_t)(blocks * 256u);
     return UR_OK;
 }
 

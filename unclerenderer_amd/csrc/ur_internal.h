@@ -24,12 +24,9 @@ struct HzbTail {
 struct ur_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    // compaction workspace of the single-launch cull (csrc/cull.hip: cull_compact_kernel), grown by ur_reserve / lazily outside
-    // graph capture: one 8-byte {epoch, count} granule per logical workgroup, and three device words {ticket, finished, epoch}
-    // that the kernel itself resets / advances (no host bookkeeping between launches)
-    unsigned long long* cull_aggregates = nullptr;
-    uint32_t* cull_ticket = nullptr;
-    uint32_t cull_groups_cap = 0;
+    // compaction workspace (grown by ur_reserve / lazily outside graph capture)
+    uint32_t* block_counts = nullptr; // one per 256-instance block
+    uint64_t* wave_masks = nullptr;   // one per 64 instances
     uint32_t ws_instances = 0;
     // sRGB8 -> linear table (256 floats), uploaded once
     float* srgb_table = nullptr;
