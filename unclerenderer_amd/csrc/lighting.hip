@@ -677,9 +677,10 @@ __device__ __forceinline__ float gt_step(float cmpBig, float t, float negBig /* 
 }
 
 // Wave-uniform conditions as SGPR integers. A `bool` that is defined in one basic block and tested or negated in another is a
-// lane mask to hipcc, and every such use goes through a VGPR (v_cndmask_b32 0/1 + v_cmp_ne_u32: the loop had four such
-// pairs, and a v_cndmask_b32 holds the issue port ~22 cycles on gfx950, tools/microbench/valu_rate.hip). The ballot is taken
-// where the comparison is made; what crosses blocks is a 32-bit scalar.
+// lane mask to hipcc, and every such use goes through a VGPR: `v_cndmask_b32 v, 0, 1, mask` + `v_cmp_ne_u32 mask', 1, v` to
+// negate a mask that `s_not_b64` would negate — two vector instructions of the 4-cycle class that cannot share an issue slot
+// with a neighbour (tools/microbench/valu_rate3/4.hip). The loop had four such pairs per iteration; with the ballot taken where
+// the comparison is made and a 32-bit scalar crossing the blocks there are none (profiles/r03_lighting_diet.txt: -1.2 us).
 __device__ __forceinline__ uint32_t flag_any(bool pred)
 {
     const uint64_t m = __builtin_amdgcn_ballot_w64(pred);
