@@ -228,12 +228,15 @@ def main():
         s["res"] = Frame.resources(W, H, row0, band, s["A"], s["B"], s["C"], s["depth_band"], s["hdr_band"], s["depth_full"], hzb, lay, tables,
                                    d_bounds, d_args, i1 - i0, i0, d_vis, d_cnt, None, s.get("ldr_band"))
 
-    # roofline leg: the Lighting launch of the sampled timed frames carries a HIP event pair ON ITS OWN DISPATCH
-    # (ur_time_next_lighting -> hipExtLaunchKernel on the stream the kernel is launched on): the pair's distance is the
-    # interval from the end of what precedes the kernel on the stream to the kernel's end as the command processor stamps
-    # them — the quantity rocprofv3's kernel trace reports for the dispatch (profiles/: same command). A sampled frame costs
-    # the queue ~8 us (the marker in front of the kernel): every second frame of a short run (the driver's --steps 20 gives
-    # 10 samples), one in eight of a long one.
+    # roofline leg: the Lighting launch of the sampled timed frames is timed by HIP events carried ON DISPATCHES
+    # (hipExtLaunchKernel on the stream the kernels are launched on): the stop event rides on the Lighting kernel's own
+    # dispatch, the start event on the cull launch directly in front of it (ur_time_next_cull / ur_time_next_lighting; the
+    # frame is exactly those two launches) — their distance is the interval from the end of what precedes the Lighting
+    # kernel to the kernel's end as the command processor stamps them, the quantity rocprofv3's kernel trace reports for the
+    # dispatch (profiles/: same command), and NOTHING enters the queue for the measurement. (Where no cull launch precedes —
+    # other --hzb-launch modes — the start event is a marker in front of the kernel, ~8 us of queue time.) A sampled frame
+    # costs ~1.7 us (the two dispatches run with their timestamps enabled): every second frame of a short run (the driver's
+    # --steps 20 gives 10 samples), one in eight of a long one.
     timed_flags = flags if args.no_light_events else (flags | urlib.UR_FRAME_TIME_LIGHTING_KERNEL)
     light_every = args.light_every if args.light_every > 0 else (2 if args.steps <= 64 else 8)
 
@@ -459,7 +462,7 @@ def main():
         "roofline": {
             "kernel": "lighting_stream_kernel<FUSED>" + (" carrying the Build HZB chain (wave pieces + tail workgroup)" if rides else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "timing": "HIP event pair carried on the kernel dispatch (hipExtLaunchKernel), timed region",
+            "timing": "HIP events carried on dispatches (hipExtLaunchKernel): end of the cull launch in front -> end of the Lighting launch, timed region",
             "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float(light_ms.min()) * 1e3,
             "median_launch_us": float(np.median(light_ms)) * 1e3,
             "bytes_per_launch_dedup": light_bytes_dedup, "frac_dedup": light_bytes_dedup / light_avg_s / 1e9 / HBM_PEAK_GBS,

@@ -167,6 +167,13 @@ int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t ca
  * has to go out in front is not timed). The reference's counterpart is the timestamp-query pair FRenderGraph puts around a
  * pass (Source/Render/RenderGraph.cpp:402-406,475-478). NULL, NULL clears what was not consumed. */
 int ur_time_next_lighting(ur_ctx* ctx, void* start_event, void* stop_event);
+/* The same for the cull: the LAST launch of the next ur_cull_indirect_args* call on the context that is a single workgroup or writes
+ * the visible list carries stop_event on its dispatch (its completion stamp). With the Lighting launch directly behind that cull on
+ * the stream — the frame of ur_frame_render with UR_FRAME_HZB_WITH_LIGHTING is exactly those two launches — this event is the START
+ * of the Lighting measurement and ur_time_next_lighting(ctx, NULL, stop) its end: hipEventElapsedTime(cull_stop, lighting_stop) is the
+ * same interval as the marker form measures (end of what precedes the kernel -> end of the kernel) with NOTHING added to the queue.
+ * One-shot; NULL clears an event that was not consumed (a words-only cull of several workgroups, or one of zero instances, takes none). */
+int ur_time_next_cull(ur_ctx* ctx, void* stop_event);
 const char* ur_last_error(void);
 const char* ur_version(void);
 

@@ -554,3 +554,28 @@ def test_temporal_aa_bit_exact(hotpath, oracle, w, h):
             if b > a:
                 hotpath.temporal_aa(d_cur, d_hist[a:b], parts[a:b], wt, use, w, h, a, b - a)
         assert torch.equal(parts, out)
+
+
+def test_cull_more_than_4096_blocks(hotpath, oracle):
+    """1.3 M instances = 5079 blocks of 256: the compaction's prefix over the block counts keeps sixteen loads per thread in flight for
+    the first 4096 blocks and loops over the rest (csrc/cull.hip: compact_kernel); words, list, count and counters bit-exact."""
+    from unclerenderer_amd import hostmath, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    torch = _torch()
+    w, h, n = 512, 288, 1_300_000
+    fc = hostmath.build_frame_constants("sponza", w, h)
+    depth = (synth.hash_unit(11, *synth._grid(w, 0, h), 0) * np.float32(0.004)).astype(np.float32)
+    lay = HzbLayout(w, h)
+    hzb = np.nan_to_num(oracle.build_hzb(depth, lay.as_list(), lay.total))
+    bounds = synth.instances_random(n, 11, center=fc.camera_position, box=300.0)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, n, True, lay.count, lay.width, lay.height, True)
+    args0 = synth.indirect_args_initial(n)
+    ref_args, ref_stats, ref_vis, ref_cnt = oracle.cull_indirect_args(consts, bounds, hzb, lay.as_list(), args0)
+    d_args, d_stats = to_device(args0), torch.zeros(2, dtype=torch.int32, device="cuda")
+    d_vis, d_cnt = torch.full((n,), -1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    hotpath.cull_indirect_args(consts, to_device(bounds), to_device(hzb), lay, d_args, d_stats, d_vis, d_cnt)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args)
+    assert int(d_cnt.cpu()[0]) == ref_cnt and ref_cnt > 4096
+    assert np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt], ref_vis)
+    assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats)

@@ -17,6 +17,8 @@
 #include "ur_internal.h"
 #include "ur_device.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -274,7 +276,12 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
     }
     const uint32_t blocks = (n + 255u) / 256u;
     if (blocks == 1) {
-        hipLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, P);
+        if (ctx->time_cull_stop != nullptr) { // ur_time_next_cull: this dispatch's completion stamp is somebody's start time
+            hipExtLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_cull_stop, 0, P);
+            ctx->time_cull_stop = nullptr;
+        } else {
+            hipLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, P);
+        }
         UR_HIP_TRY(hipGetLastError());
         return UR_OK;
     }
@@ -289,7 +296,12 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
     hipLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, P);
     UR_HIP_TRY(hipGetLastError());
     if (visible_idx) {
-        hipLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, P, blocks);
+        if (ctx->time_cull_stop != nullptr) { // (the call's LAST launch carries the event)
+            hipExtLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, nullptr, ctx->time_cull_stop, 0, P, blocks);
+            ctx->time_cull_stop = nullptr;
+        } else {
+            hipLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, P, blocks);
+        }
         UR_HIP_TRY(hipGetLastError());
     }
     return UR_OK;

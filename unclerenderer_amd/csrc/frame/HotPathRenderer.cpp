@@ -200,6 +200,7 @@ struct ur_frame
     size_t LightHead = 0, LightCount = 0;
     bool bRecordAfter = false; // this frame's bracket gets the third event (UR_FRAME_TIME_LIGHTING_RECORD_COST)
     bool bKernelEvents = false; // UR_FRAME_TIME_LIGHTING_KERNEL: the pair rides on the Lighting dispatch itself, nothing is recorded around it
+    bool bStartOnCull = false;  // ... and this frame's START event was handed to the cull launch directly in front of the Lighting launch
     ur_frame(ur_ctx* Ctx, hipStream_t Stream, uint32 Frames, int Rank, int World) : Cmd(Ctx, Stream, Frames, Rank, World), Renderer(&Device) {}
 };
 
@@ -219,9 +220,11 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
         if (f->bKernelEvents) {
             if (begin) {
                 f->LightHead = f->LightCount % f->LightEvents.size();
-                // start = a marker the runtime puts in front of the kernel, stop = bound to the kernel's own dispatch (its completion
-                // signal's end stamp). (One event alone measures nothing on this runtime: hipEventElapsedTime(e, e) is 0.)
-                (void)ur_time_next_lighting(f->Cmd.GetContext(), f->LightEvents[f->LightHead].first, f->LightEvents[f->LightHead].second);
+                // stop = bound to the Lighting kernel's own dispatch (its completion signal's end stamp). start = the end stamp of the
+                // dispatch directly in front of it when that is this frame's cull launch (ur_frame_render handed it the event: NOTHING
+                // enters the queue for the measurement), else a marker the runtime puts in front of the kernel (~8 us of queue time).
+                // (One event alone measures nothing on this runtime: hipEventElapsedTime(e, e) is 0.)
+                (void)ur_time_next_lighting(f->Cmd.GetContext(), f->bStartOnCull ? nullptr : f->LightEvents[f->LightHead].first, f->LightEvents[f->LightHead].second);
             } else {
                 (void)ur_time_next_lighting(f->Cmd.GetContext(), nullptr, nullptr); // (a launch that failed validation consumed nothing)
                 f->LightEvents[f->LightHead].has_after = false;
@@ -333,7 +336,21 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     const bool chain_with_lighting = (flags & UR_FRAME_HZB_WITH_LIGHTING) != 0 && !O.bAsyncCompute;
     const bool tail_with_lighting = (chain_with_lighting || (flags & UR_FRAME_HZB_TAIL_WITH_LIGHTING) != 0) && !O.bAsyncCompute;
     if (tail_with_lighting) (void)ur_defer_hzb_tail(f->Cmd.GetContext(), chain_with_lighting ? 2 : 1);
+    f->bStartOnCull = false;
+    if (f->bKernelEvents && chain_with_lighting && O.bEnableIndirectDraw && O.bHZBEnabled && O.bDoDepthPrepass && R.IndirectArgs && R.ModelBounds &&
+        R.IndirectCommandCount != 0) {
+        // Two launches in this frame, the cull and the Lighting launch that carries Build HZB: the cull's own completion stamp is the
+        // start of the Lighting measurement. (Events of the ring are created here if this is its first use.)
+        constexpr size_t kRing = 1024;
+        if (f->LightEvents.size() < kRing && f->LightCount == f->LightEvents.size()) {
+            hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventCreate(&c) == hipSuccess) f->LightEvents.push_back({a, b, c, false, false});
+        }
+        if (!f->LightEvents.empty() && ur_time_next_cull(f->Cmd.GetContext(), f->LightEvents[f->LightCount % f->LightEvents.size()].first) == UR_OK)
+            f->bStartOnCull = true;
+    }
     const int rc = f->Renderer.RenderFrame(f->Cmd, R, K, O);
+    if (f->bStartOnCull) (void)ur_time_next_cull(f->Cmd.GetContext(), nullptr); // (a cull that launched nothing consumed nothing)
     if (tail_with_lighting) {
         const int rc2 = ur_defer_hzb_tail(f->Cmd.GetContext(), 0); // launches the tail on its own if no Lighting launch took it
         // a riding tail that gave up waiting (a bounded wait inside an earlier Lighting launch) is reported here, once: UR_ETIMEOUT

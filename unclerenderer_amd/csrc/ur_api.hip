@@ -213,6 +213,13 @@ int ur_time_next_lighting(ur_ctx* ctx, void* start_event, void* stop_event)
     return UR_OK;
 }
 
+int ur_time_next_cull(ur_ctx* ctx, void* stop_event)
+{
+    if (!ctx) { set_error("ur_time_next_cull: null context"); return UR_EINVAL; }
+    ctx->time_cull_stop = static_cast<hipEvent_t>(stop_event);
+    return UR_OK;
+}
+
 int ur_flush(ur_ctx* ctx)
 {
     if (!ctx) { set_error("ur_flush: null context"); return UR_EINVAL; }

@@ -53,6 +53,7 @@ struct ur_ctx {
     uint32_t* hzb_timed_out_dev = nullptr; // its device address
     // ur_time_next_lighting: events the next Lighting launch carries on its dispatch (hipExtLaunchKernel); consumed by it
     hipEvent_t time_start = nullptr, time_stop = nullptr;
+    hipEvent_t time_cull_stop = nullptr; // ur_time_next_cull: carried by the last launch of the next cull call that lists or is one block
 };
 
 namespace ur {

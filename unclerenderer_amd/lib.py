@@ -125,6 +125,7 @@ SIGNATURES = {
     "ur_debug_set_hzb_timeout": (C.c_int, [_VP]),
     "ur_debug_timeline": (C.c_int, [_VP, _VP, _U32]),
     "ur_time_next_lighting": (C.c_int, [_VP, _VP, _VP]),
+    "ur_time_next_cull": (C.c_int, [_VP, _VP]),
     "ur_last_error": (C.c_char_p, []),
     "ur_version": (C.c_char_p, []),
     "ur_hzb_layout": (_U32, [_U32, _U32, C.POINTER(MipDesc), C.POINTER(_U32)]),
