@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-3 evidence bundle: tests, profiles (kernel trace + PMC traffic passes), per-kernel table, bench lines
+# The round's evidence bundle (run on the GPU box): GPU tests, kernel-trace + PMC traffic passes, per-kernel table, bench lines.
+#   gpurun --timeout 1100 -- "bash tools/evidence_bundle.sh"; then: python tools/collect_profiles.py r03 r03
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 (timeout -k 10 400 python -m pytest tests -m gpu -x -q > gpurun_out/t7.log 2>&1; echo "rc=$?" >> gpurun_out/t7.log; tail -3 gpurun_out/t7.log)
