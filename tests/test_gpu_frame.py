@@ -109,3 +109,71 @@ def test_frame_passes_and_parity(hotpath, oracle):
     names = {t[0] for t in frame.timing_stats()}
     assert {"GPU Culling", "Build HZB", "Lighting", "Sky"} <= names
     frame.close()
+
+
+def test_lighting_timing_forms_leave_the_frame_alone(hotpath):
+    """The three ways a Lighting pass is timed — an event bracket on the stream (UR_FRAME_TIME_LIGHTING), the pair carried on the
+    Lighting dispatch (UR_FRAME_TIME_LIGHTING_KERNEL: begin = the end of the cull dispatch in front when the frame is exactly those
+    two launches, ur_time_next_cull), and ur_time_next_lighting called directly — report positive durations of the same order
+    and change no byte of the frame."""
+    import torch
+    from unclerenderer_amd import hostmath, lib, synth
+    from unclerenderer_amd.hotpath import Frame, HzbLayout, to_device
+    w, h, n = 256, 144, 300
+    fc = hostmath.build_frame_constants("sponza", w, h, shadow_size=128, env_mip_count=5)
+    g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 37)
+    shadow, env, lut = synth.shadow_map_noise(128, 37), synth.env_cube_procedural(16, 5), synth.brdf_lut_procedural(64, 16)
+    tables = hotpath.make_tables(to_device(shadow), hotpath.stage_env_cube(env, 16, 5), 16, 5, to_device(lut))
+    lay = HzbLayout(w, h)
+    bounds = to_device(synth.instances_random(n, 37, center=fc.camera_position, box=60.0))
+    args0 = synth.indirect_args_initial(n)
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, True)
+    base = lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY
+
+    def run(flags, frames=6):
+        frame = Frame(hotpath)
+        d_hzb = torch.zeros(lay.total, device="cuda")
+        d_args, d_stats = to_device(args0), torch.zeros(2, dtype=torch.int32, device="cuda")
+        d_vis, d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+        hdr = None
+        for _ in range(frames):
+            d_args.copy_(to_device(args0)); d_stats.zero_()
+            hdr = to_device(g.hdr)
+            res = Frame.resources(w, h, 0, h, dA, dB, dC, dD, hdr, dD, d_hzb, lay, tables, bounds, d_args, n, 0, d_vis, d_cnt, d_stats)
+            frame.render(res, consts, fc.scene, fc.sky, flags)
+        torch.cuda.synchronize()
+        times = frame.lighting_times_ms()
+        frame.close()
+        return (hdr.cpu(), d_hzb.cpu(), d_args.cpu(), d_vis.cpu(), d_cnt.cpu(), d_stats.cpu()), times
+
+    for ride in (0, lib.UR_FRAME_HZB_WITH_LIGHTING):  # separate Build HZB launches / the chain riding in the Lighting launch
+        ref, t0 = run(base | ride)
+        assert t0.size == 0
+        for timed in (lib.UR_FRAME_TIME_LIGHTING, lib.UR_FRAME_TIME_LIGHTING_KERNEL):
+            out, t = run(base | ride | timed)
+            assert t.size == 6 and (t > 0).all() and (t < 5.0).all(), (ride, timed, t)
+            for a, b in zip(ref, out):
+                assert torch.equal(a, b), (ride, timed)
+
+    # the entry point itself: the pair rides on the next Lighting dispatch and is consumed by it
+    hdr = to_device(g.hdr)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()  # (torch creates the HIP event at the first record)
+    torch.cuda.synchronize()
+    hotpath.time_next_lighting(e0, e1)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, hdr, w, h)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    assert 0.0 < ms < 5.0
+    hdr_b = to_device(g.hdr)
+    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, hdr_b, w, h)  # consumed: this launch carries nothing
+    torch.cuda.synchronize()
+    assert torch.equal(hdr, hdr_b)
+    assert abs(e0.elapsed_time(e1) - ms) < 1e-6
+    # a stop event is required when a start event is given
+    L = hotpath._L
+    import ctypes as C
+    assert L.ur_time_next_lighting(hotpath._ctx, C.c_void_p(e0.cuda_event), None) == lib.UR_EINVAL
+    assert L.ur_time_next_cull(hotpath._ctx, None) in (lib.UR_OK, lib.UR_EINVAL)  # clearing is allowed or rejected, never a crash
+    hotpath.time_next_lighting(None, None)
