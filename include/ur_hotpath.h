@@ -215,11 +215,14 @@ int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_fl
 
 /* ---- DeferredLighting / SkyAtmosphere ---------------------------------------------------------- */
 
-/* Number of half4 texels of the bordered cube for (base_size, mip_count); 0 on bad arguments. */
+/* Number of half4 texels ur_stage_env_cube() writes for (base_size, mip_count): the bordered faces, 6 (N+2)^2 per mip, followed
+ * by the same texels as row pairs, 12 (N+2)(N+1) per mip; 0 on bad arguments. */
 size_t ur_env_cube_texels(uint32_t base_size, uint32_t mip_count);
 /* Stage an RGBA16F cube in DDS order (face-major, mips inner; TextureLoader.cpp:276-315) from HOST
  * memory into the device layout the lighting kernel samples: mip-major, 6 faces per mip, each face
- * (N+2)x(N+2) with a one-texel border holding the seamless neighbours from the adjacent faces.
+ * (N+2)x(N+2) with a one-texel border holding the seamless neighbours from the adjacent faces; behind all mips the same faces
+ * once more as ROW PAIRS (entry (f, j, i) = {texel (i, j), texel (i, j+1)}, 16 bytes, pair-rows contiguous), so that a 2x2
+ * bilinear footprint is 32 contiguous bytes: the layout the streaming kernel gathers its prefiltered taps from.
  * dst_device must hold ur_env_cube_texels() texels. Synchronous (setup time, like the DDS upload). */
 int ur_stage_env_cube(ur_ctx* ctx, const ur_half4* src_host, uint32_t base_size, uint32_t mip_count,
                       ur_half4* dst_device);

@@ -366,9 +366,19 @@ def test_stage_env_cube_matches_folding_rule(hotpath, oracle):
     from unclerenderer_amd import synth
     env = synth.env_cube_procedural(16, 5)
     env[:, 0] = (np.arange(env.shape[0]) & 0x3FF).astype(np.uint16)  # make every texel distinguishable
-    got = hotpath.stage_env_cube(env, 16, 5).cpu().numpy().view(np.uint16)
-    ref = oracle.stage_env_cube(env, 16, 5)
-    assert np.array_equal(got, ref)
+    got = hotpath.stage_env_cube(env, 16, 5).cpu().numpy().view(np.uint16).reshape(-1, 4)
+    ref = oracle.stage_env_cube(env, 16, 5).reshape(-1, 4)
+    nb = ref.shape[0]
+    assert np.array_equal(got[:nb], ref)  # the bordered faces
+    # behind them the same faces as row pairs: entry (f, j, i) = {texel (i, j), texel (i, j + 1)}
+    off, boff = nb, 0
+    for m in range(5):
+        E = max(1, 16 >> m) + 2
+        faces = ref[boff:boff + 6 * E * E].reshape(6, E, E, 4)
+        pairs = np.stack([faces[:, :-1], faces[:, 1:]], axis=3)  # (6, E-1, E, 2, 4)
+        assert np.array_equal(got[off:off + 12 * E * (E - 1)], pairs.reshape(-1, 4)), m
+        off += 12 * E * (E - 1); boff += 6 * E * E
+    assert off == got.shape[0]
 
 
 def test_lighting_rejects_non_rigid_view(hotpath):

@@ -552,7 +552,7 @@ constexpr uint32_t kLutW = 128, kLutH = 32, kLutE = kLutW + 2;    // streaming k
 constexpr uint32_t kLdsSrgb = 0;                                    // 256 floats
 constexpr uint32_t kLdsIrrBytes = 6 * 9 * 64;                       // 54 cells x 64 B
 constexpr uint32_t kLdsWork = 1024 + 17 * 32 + kLdsIrrBytes;        // [0] the workgroup's tile counter, [1] waves that left the loop (16 bytes reserved)
-constexpr uint32_t kLdsMip = 1024;                                  // 17 x 32 B: per-mip cube constants (MipEntry)
+constexpr uint32_t kLdsMip = 1024;                                  // 17 x 16 B: per-mip cube constants (MipEntry)
 constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradiance mip (N <= 2) as per-cell polynomials: up to 6 * 3 * 3 cells of 64 B
 constexpr uint32_t kLdsHzb = kLdsWork + 16;                         // 80 floats per wave: mip-2 / mip-3 scratch of the waves that walk HZB pieces
 constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
@@ -696,7 +696,9 @@ __device__ __forceinline__ uint32_t flag_all(bool pred) // (every lane of the wa
     return r;
 }
 
-struct __attribute__((aligned(16))) MipEntry { float Nf, Ef, EEf, offf; uint32_t rowBytes, pad0, pad1, pad2; };
+// Per-mip constants of the cube's ROW-PAIR section (ur_stage_env_cube): N, the entries per pair-row E = N + 2, the entries per face
+// E (E - 1), and the mip's first entry counted from the start of the buffer - all in 16-byte entries, as floats (exact below 2^24).
+struct __attribute__((aligned(16))) MipEntry { float Nf, Ef, EEf, offf; };
 
 // input-only "these registers are needed here": hipcc puts the s_waitcnt of pending loads in front of the statement
 __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u32x4_t& c, const u32x4_t& d)
@@ -863,7 +865,13 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
         if (threadIdx.x < 17u) {
             const uint32_t m = min(threadIdx.x, p.envMips - 1u); // entry [envMips] repeats the last mip (weight 0 when it is read)
             const uint32_t N = max(1u, p.envBase >> m), E = N + 2u;
-            mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * E), (float)p.envMipOffset[m], E * 8u, 0u, 0u, 0u};
+            uint32_t bordered = 0u, before = 0u; // texels of all bordered mips; pair entries of the mips in front of this one
+            for (uint32_t k = 0; k < p.envMips; ++k) {
+                const uint32_t e = max(1u, p.envBase >> k) + 2u;
+                bordered += 6u * e * e;
+                if (k < m) before += 6u * e * (e - 1u);
+            }
+            mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * (E - 1u)), (float)(bordered / 2u + before)};
         }
 #pragma unroll
         for (uint32_t k = 0; k < kLutTrips; ++k) {
@@ -1012,7 +1020,6 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const float fl = __builtin_amdgcn_fractf(lvl);
             const MipEntry* me = mipT + (uint32_t)lvl;
             const float4a e0 = *reinterpret_cast<const float4a*>(me), e1 = *reinterpret_cast<const float4a*>(me + 1);
-            const uint32_t rowB0 = me[0].rowBytes, rowB1 = me[1].rowBytes;
             const float faceR = __builtin_amdgcn_cubeid(Rw.x, Rw.y, Rw.z);
             const float invR = rcp(fabsf(__builtin_amdgcn_cubema(Rw.x, Rw.y, Rw.z)));
             f2_t uvR;
@@ -1024,17 +1031,18 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const f2_t xy = f2(fmaf(uvR.x, e0.x, 0.5f), fmaf(uvR.y, e0.x, 0.5f)); // bordered coordinates in [0.5, N + 0.5]
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
                 f0 = f2(xy.x - i0, xy.y - j0);
-                const uint32_t o = (uint32_t)(fmaf(faceR, e0.z, fmaf(j0, e0.y, i0)) + e0.w) * 8u;
+                // row-pair section: the footprint's 32 contiguous bytes {(i0, j0), (i0, j0 + 1)} {(i0 + 1, j0), (i0 + 1, j0 + 1)}
+                const uint32_t o = (uint32_t)(fmaf(faceR, e0.z, fmaf(j0, e0.y, i0)) + e0.w) * 16u;
                 p0a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
-                p0b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB0));
+                p0b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + 16u));
             }
             {
                 const f2_t xy = f2(fmaf(uvR.x, e1.x, 0.5f), fmaf(uvR.y, e1.x, 0.5f));
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
                 f1 = f2(xy.x - i0, xy.y - j0);
-                const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 8u;
+                const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 16u;
                 p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
-                p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + rowB1));
+                p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + 16u));
             }
             const float faceN = __builtin_amdgcn_cubeid(Nxy.x, Nxy.y, Nz);
             const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nxy.x, Nxy.y, Nz)));
@@ -1166,13 +1174,14 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 b10 = b0 * fx1; b00 = b0 - b10; b11 = b1 * fx1; b01 = b1 - b11;
                 asm volatile("" : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11));
                 float x, y, z;
+                // (p.a = {texel (i0, j0), texel (i0, j0 + 1)}, p.b = the same of column i0 + 1; summed in the order 00, 10, 01, 11)
                 x = mul_lo(p0a.x, a00); y = mul_hi(p0a.x, a00); z = mul_lo(p0a.y, a00);
-                x = mix_lo(x, p0a.z, a10); y = mix_hi(y, p0a.z, a10); z = mix_lo(z, p0a.w, a10);
-                x = mix_lo(x, p0b.x, a01); y = mix_hi(y, p0b.x, a01); z = mix_lo(z, p0b.y, a01);
+                x = mix_lo(x, p0b.x, a10); y = mix_hi(y, p0b.x, a10); z = mix_lo(z, p0b.y, a10);
+                x = mix_lo(x, p0a.z, a01); y = mix_hi(y, p0a.z, a01); z = mix_lo(z, p0a.w, a01);
                 x = mix_lo(x, p0b.z, a11); y = mix_hi(y, p0b.z, a11); z = mix_lo(z, p0b.w, a11);
                 x = mix_lo(x, p1a.x, b00); y = mix_hi(y, p1a.x, b00); z = mix_lo(z, p1a.y, b00);
-                x = mix_lo(x, p1a.z, b10); y = mix_hi(y, p1a.z, b10); z = mix_lo(z, p1a.w, b10);
-                x = mix_lo(x, p1b.x, b01); y = mix_hi(y, p1b.x, b01); z = mix_lo(z, p1b.y, b01);
+                x = mix_lo(x, p1b.x, b10); y = mix_hi(y, p1b.x, b10); z = mix_lo(z, p1b.y, b10);
+                x = mix_lo(x, p1a.z, b01); y = mix_hi(y, p1a.z, b01); z = mix_lo(z, p1a.w, b01);
                 x = mix_lo(x, p1b.z, b11); y = mix_hi(y, p1b.z, b11); z = mix_lo(z, p1b.w, b11);
                 prexy = f2(x, y); prez = z;
                 if (!IRR_LDS) {
@@ -1494,7 +1503,10 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     // (the streaming kernel addresses the staged cube in fp32: texel indices must stay below 2^24, i.e. base sizes up to 1024)
     uint64_t env_texels = 0;
     if (mode != UR_MODE_SKY)
-        for (uint32_t m = 0; m < p.envMips; ++m) { const uint64_t e = (uint64_t)std::max(1u, p.envBase >> m) + 2u; env_texels += 6u * e * e; }
+        for (uint32_t m = 0; m < p.envMips; ++m) { // (the gathers address the row-pair section behind the bordered mips, in 16-byte entries)
+            const uint64_t e = (uint64_t)std::max(1u, p.envBase >> m) + 2u;
+            env_texels += 6u * e * e / 2u + 6u * e * (e - 1u);
+        }
     const uint64_t n_tiles = (uint64_t)(w / 16u) * ((rows + 3u) / 4u);
     const uint64_t magic_err = w >= 16u ? ((1ull << 32) / (w / 16u) + 1ull) * (w / 16u) - (1ull << 32) : 0;
     // (the streaming kernel takes its dot products in world space: the rotation must be orthonormal to rounding; its tile DMA
