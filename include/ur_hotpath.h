@@ -233,11 +233,11 @@ int ur_stage_env_cube(ur_ctx* ctx, const ur_half4* src_host, uint32_t base_size,
  * gbuf_c: R8G8B8A8_UNORM_SRGB (R in the low byte); hdr_inout: RGBA16F holding (emissive, 1).
  * Like the reference it shades EVERY pixel, so cleared G-buffer pixels come out NaN.
  * Numerics: within max(1e-3, one fp16 ulp) of a scalar fp32 evaluation of the HLSL per channel (tests/test_gpu_parity.py).
- * Where the reference shades anything, this returns UR_EUNSUPPORTED for: a ViewInverse whose upper 3x3 is not a rotation
- * to 1e-3 (the kernels carry vectors between view and world space as rigid transforms; a camera built by LookToLH always
- * is), a shadow map smaller than 3x3 texels with ShadowStrength > 0, and a band of 2^29 pixels or more in one call.
+ * The one input the reference would shade and this returns UR_EUNSUPPORTED for is a band of 2^29 pixels or more in one call.
  * Everything else is shaded by one of two kernels (a streaming one for the common shapes, a per-tile one for the rest: a
- * width that is not a multiple of 16, a perspective light, a LUT that is not 128x32, ...) with the same values. */
+ * width that is not a multiple of 16, a perspective light, a LUT that is not 128x32, a ViewInverse that is not a rigid
+ * transform or whose origin is not CameraPosition - world-space vectors are then formed literally -, a shadow map below
+ * 3x3 texels, ...) with the same values. */
 int ur_deferred_lighting(ur_ctx* ctx, const ur_scene_constants* scene, const ur_half4* gbuf_a,
                          const ur_half4* gbuf_b, const uint32_t* gbuf_c, const ur_lighting_tables* tables,
                          ur_half4* hdr_inout, uint32_t w, uint32_t h, uint32_t row0, uint32_t rows);

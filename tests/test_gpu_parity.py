@@ -381,16 +381,54 @@ def test_stage_env_cube_matches_folding_rule(hotpath, oracle):
     assert off == got.shape[0]
 
 
-def test_lighting_rejects_non_rigid_view(hotpath):
-    from unclerenderer_amd import lib
+@pytest.mark.parametrize("case", ["sheared_view", "scaled_view", "camera_elsewhere", "shadow_2x2", "shadow_1x1", "shadow_2x5"])
+def test_lighting_inputs_outside_the_fast_paths(hotpath, oracle, case):
+    """What the reference never produces but its shader would shade all the same (DeferredLighting.hlsl:55,76-84): a
+    ViewInverse that is not rigid, a CameraPosition that is not its origin, a shadow map too small for a 3x3 block. They take
+    the per-tile kernel with the world-space vectors formed literally / every tap through the bordered PCF, and agree with the
+    oracle like every other input (rounds 1-2 returned UR_EUNSUPPORTED)."""
+    from unclerenderer_amd import synth
     from unclerenderer_amd.hotpath import to_device
-    w, h = 16, 8
-    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=1, mode="iid")
+    torch = _torch()
+    w, h = 96, 40
+    ss = {"shadow_2x2": (2, 2), "shadow_1x1": (1, 1), "shadow_2x5": (2, 5)}.get(case)
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=21, mode="scene")
+    if case == "sheared_view":
+        fc.scene.ViewInverse[1] += 0.35   # row 0 no longer orthogonal to row 1
+        fc.scene.ViewInverse[6] -= 0.2
+    elif case == "scaled_view":
+        for k in (0, 1, 2):
+            fc.scene.ViewInverse[k] *= 1.7  # row 0 of the 3x3 scaled
+    elif case == "camera_elsewhere":
+        fc.scene.CameraPosition[0] += 3.0
+        fc.scene.CameraPosition[1] -= 1.5
+    else:
+        sw, sh_ = ss
+        shadow = (0.2 + 0.7 * np.random.default_rng(5).random((sh_, sw))).astype(np.float32)
+        fc.scene.ShadowMapSize[0], fc.scene.ShadowMapSize[1] = float(sw), float(sh_)
     tables = _device_tables(hotpath, shadow, env, lut)
-    fc.scene.ViewInverse[0] = 2.0
-    with pytest.raises(lib.UrError) as e:
-        hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, to_device(g.hdr), w, h)
-    assert e.value.code == lib.UR_EUNSUPPORTED
+    ref, fragile = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 32, 6, lut, g.hdr, w, h, want_fragile=True)
+    d = to_device(g.hdr)
+    hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, d, w, h)
+    torch.cuda.synchronize()
+    nbad, worst, _ = hdr_mismatch(d.cpu().numpy().view(np.uint16), ref, exclude=fragile)
+    assert nbad == 0, (case, nbad, worst)
+    assert (~fragile.astype(bool)).sum() > 0.8 * w * h
+    if ss is None:  # the world-space vectors must actually differ from the rigid ones: the rigid path on these inputs fails
+        rigid = oracle.deferred_lighting(_rigid_copy(fc.scene), g.A, g.B, g.C, shadow, env, 32, 6, lut, g.hdr, w, h)
+        assert hdr_mismatch(rigid, ref)[0] > 0
+
+
+def _rigid_copy(scene):
+    import copy
+    from unclerenderer_amd import hostmath
+    c = copy.deepcopy(scene)
+    fc = hostmath.build_frame_constants("sponza", 96, 40, shadow_size=256)
+    for k in range(16):
+        c.ViewInverse[k] = fc.scene.ViewInverse[k]
+    for k in range(3):
+        c.CameraPosition[k] = fc.scene.CameraPosition[k]
+    return c
 
 
 # ---------------------------------------------------------------------------------------------------------------------

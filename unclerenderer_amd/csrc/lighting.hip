@@ -71,6 +71,9 @@ struct LightingParams {
     float L[3];          // normalize(mul(float4(LightDirection,0), View).xyz)
     float R[9];          // (float3x3)ViewInverse, row-major
     float SQ[12];        // rows 0..2 of (ViewInverse * LightViewProjection), columns x,y,z,w : applied to the camera ray (a,b,1)
+    float VIt[3], camPos[3]; // row 3 of ViewInverse, CameraPosition: the general path below (general != 0)
+    uint32_t general;    // ViewInverse is not a rigid transform, or CameraPosition is not its origin: world vectors are formed literally
+    uint32_t shadowSmall; // a shadow map below 3x3 texels: every pixel takes the bordered PCF
     float ST[4];         // row 3 of the same matrix
     float lightRGB[3];   // LightIntensity * LightColor
     float shadowStrength, shadowBias;
@@ -365,16 +368,37 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
 
     // ---- issue every gather ------------------------------------------------------------------------------------------
     // IBL: world vectors are the view-space ones rotated by (float3x3)ViewInverse; reflect(-V, N) = 2 N (N.V) - V
-    const float t2 = 2.0f * NdotVraw;
-    const CubeUV cr = cube_face(rot(f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z)), p.R));
-    const CubeUV cn = cube_face(rot(N, p.R));
+    // With a rigid view matrix whose origin is CameraPosition (every camera the reference builds) that rotation keeps lengths and
+    // angles, worldView is the rotated V and dot(worldNormal, worldView) = N.V. Otherwise (uniform, p.general) the vectors are formed
+    // as the shader writes them: worldPos = viewPos * ViewInverse, worldView = normalize(CameraPosition - worldPos),
+    // worldNormal = normalize(normal * (float3x3)ViewInverse) (DeferredLighting.hlsl:55,76-78,84).
+    F3 wR = f3(0.0f, 0.0f, 0.0f), wN = f3(0.0f, 0.0f, 0.0f);
+    float NdotVibl = NdotV;
+    if (p.general == 0u) {
+        const float t2 = 2.0f * NdotVraw;
+        wR = rot(f3(fmaf(t2, N.x, -V.x), fmaf(t2, N.y, -V.y), fmaf(t2, N.z, -V.z)), p.R);
+        wN = rot(N, p.R);
+    } else {
+        const F3 wp = rot(f3(ra * viewZ, rb * viewZ, viewZ), p.R);
+        F3 wv = f3(p.camPos[0] - (wp.x + p.VIt[0]), p.camPos[1] - (wp.y + p.VIt[1]), p.camPos[2] - (wp.z + p.VIt[2]));
+        const float wvr = rsq(dot(wv, wv));
+        wv = f3(wv.x * wvr, wv.y * wvr, wv.z * wvr);
+        wN = rot(N, p.R);
+        const float wnr = rsq(dot(wN, wN));
+        wN = f3(wN.x * wnr, wN.y * wnr, wN.z * wnr);
+        const float nv = dot(wN, wv);
+        wR = f3(fmaf(2.0f * nv, wN.x, -wv.x), fmaf(2.0f * nv, wN.y, -wv.y), fmaf(2.0f * nv, wN.z, -wv.z)); // reflect(-worldView, worldNormal)
+        NdotVibl = sat(nv);
+    }
+    const CubeUV cr = cube_face(wR);
+    const CubeUV cn = cube_face(wN);
     const float lvl = fminf(fmaxf(roughness * p.maxMip, 0.0f), (float)(p.envMips - 1u));
     const uint32_t m0 = (uint32_t)lvl, m1 = min(m0 + 1u, p.envMips - 1u);
     const float fl = lvl - (float)m0; // m1 == m0 only when fl == 0: the second mip then carries weight 0
     const CubeTaps pre0 = cube_taps_load(p.env, mipOffset[m0], max(1u, p.envBase >> m0), cr);
     const CubeTaps pre1 = cube_taps_load(p.env, mipOffset[m1], max(1u, p.envBase >> m1), cr);
     const CubeTaps irr0 = cube_taps_load(p.env, p.irrOffset0, p.irrN0, cn);
-    const LutTaps lut = lut_taps_load(p, NdotV, roughness);
+    const LutTaps lut = lut_taps_load(p, NdotVibl, roughness);
     // The shadow term multiplies NdotL: a wave whose every pixel faces away from the light skips the PCF altogether
     // (same result: direct = 0). Coherent G-buffers make this common (ceilings, walls turned from the sun).
     const float NdotL = sat(dot(N, L));
@@ -393,7 +417,8 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
         sv = fmaf(fmaf(viewZ, qy, p.ST[1]) * iw, -0.5f, 0.5f);
         cmp = fmaf(viewZ, qz, p.ST[2]) * iw - p.shadowBias;
         lit = su >= 0.0f && sv >= 0.0f && su <= 1.0f && sv <= 1.0f;
-        sh = shadow_taps_load(p, su, sv);
+        if (p.shadowSmall == 0u) sh = shadow_taps_load(p, su, sv); // (uniform; the 3x3 block needs a map of at least 3x3 texels)
+        else sh = ShadowTaps{};
     }
     const F3 albedo = f3(srgb[gc & 0xFFu], srgb[(gc >> 8) & 0xFFu], srgb[(gc >> 16) & 0xFFu]);
 
@@ -421,7 +446,7 @@ __device__ __forceinline__ F3 shade_pixel(const LightingParams& p, const float* 
     // ---- filter ---------------------------------------------------------------------------------------------------------------
     float shadow = 1.0f;
     if (wave_lit) {
-        const bool fast = sh.ia >= 0 && sh.ja >= 0 && sh.ia + 2 < p.shadowWi && sh.ja + 2 < p.shadowHi;
+        const bool fast = p.shadowSmall == 0u && sh.ia >= 0 && sh.ja >= 0 && sh.ia + 2 < p.shadowWi && sh.ja + 2 < p.shadowHi;
         float s = shadow_taps_filter(sh, cmp);
         if (__builtin_expect(lit && !fast, 0)) {
             const float xa = fmaf(su, p.shadowW, -0.5f), ya = fmaf(sv, p.shadowH, -0.5f);
@@ -1412,11 +1437,15 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
             for (int j = i; j < 3; ++j) {
                 const float d = VI[i * 4] * VI[j * 4] + VI[i * 4 + 1] * VI[j * 4 + 1] + VI[i * 4 + 2] * VI[j * 4 + 2];
                 ortho_err = std::fmax(ortho_err, std::fabs(d - (i == j ? 1.0f : 0.0f)));
-                if (std::fabs(d - (i == j ? 1.0f : 0.0f)) > 1e-3f) {
-                    set_error("ViewInverse is not a rigid transform (row %d . row %d = %g)", i, j, d);
-                    return UR_EUNSUPPORTED;
-                }
             }
+        // Every camera the reference builds is rigid with CameraPosition as its origin (RendererUtils.cpp: View from LookTo, its
+        // inverse, the same position). Anything else takes the per-tile kernel's literal world-space vectors.
+        float cam_err = 0.0f;
+        for (int j = 0; j < 3; ++j) {
+            p.VIt[j] = VI[12 + j]; p.camPos[j] = S->CameraPosition[j];
+            cam_err = std::fmax(cam_err, std::fabs(VI[12 + j] - S->CameraPosition[j]) / std::fmax(1.0f, std::fabs(VI[12 + j])));
+        }
+        p.general = (!(ortho_err <= 1e-3f) || !(cam_err <= 1e-5f)) ? 1u : 0u;
         p.invP11 = 1.0f / S->Projection[0];
         p.invP22 = 1.0f / S->Projection[5];
         const float* V = S->View;
@@ -1439,10 +1468,7 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         p.shadowTexelX = 1.0f / S->ShadowMapSize[0]; p.shadowTexelY = 1.0f / S->ShadowMapSize[1];
         p.shadow = T->shadow_map;
         shadows = p.shadowStrength > 0.0f;
-        if (shadows && (p.shadowWi < 3 || p.shadowHi < 3)) {
-            set_error("shadow maps smaller than 3x3 texels are not supported");
-            return UR_EUNSUPPORTED;
-        }
+        p.shadowSmall = (shadows && (p.shadowWi < 3 || p.shadowHi < 3)) ? 1u : 0u; // per-tile kernel, every tap through the bordered PCF
         if (shadows && (p.shadow == nullptr || p.shadowWi <= 0 || p.shadowHi <= 0)) {
             set_error("ShadowStrength > 0 but no shadow map / ShadowMapSize");
             return UR_EINVAL;
@@ -1513,7 +1539,7 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     // moves 16 bytes per lane: 16-byte-aligned band buffers)
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
                                  reinterpret_cast<uintptr_t>(p.depth) | reinterpret_cast<uintptr_t>(p.hdr);
-    if (use_stream && mode != UR_MODE_SKY && (align_bits & 15u) == 0 && ortho_err <= 1e-5f && w % 16u == 0 && w >= 32u /* the magic of one tile per row does not fit 32 bits */ && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f && env_texels < (1ull << 24)) {
+    if (use_stream && mode != UR_MODE_SKY && (align_bits & 15u) == 0 && ortho_err <= 1e-5f && p.general == 0u && p.shadowSmall == 0u && w % 16u == 0 && w >= 32u /* the magic of one tile per row does not fit 32 bits */ && magic_err * n_tiles < (1ull << 32) && p.lutW == kLutW && p.lutH == kLutH && p.irrFrac == 0.0f && env_texels < (1ull << 24)) {
         bool ok = true;
         StreamHot& h = p.hot;
         if (shadows) {
