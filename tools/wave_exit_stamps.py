@@ -26,12 +26,14 @@ MAXG = 256
 ENTRY_OLD = "    ur::timeline_entry(p.timeline);\n    if (blockIdx.x >= p.hot.groups) {"
 ENTRY_NEW = ("    ur::timeline_entry(p.timeline);\n"
              "    if (p.timeline != nullptr && (threadIdx.x & 63u) == 0u && blockIdx.x < %dU)\n"
-             "        p.timeline[2u + %du + blockIdx.x * %du + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();\n"
-             "    if (blockIdx.x >= p.hot.groups) {") % (MAXG, MAXG * WAVES, WAVES)
+             "        { p.timeline[2u + %du + blockIdx.x * %du + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();\n"
+             "          p.timeline[2u + %du + blockIdx.x * %du + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); }\n"
+             "    if (blockIdx.x >= p.hot.groups) {") % (MAXG, MAXG * WAVES, WAVES, 3 * MAXG * WAVES, WAVES)
 EXIT_OLD = "    unsigned long long* const tl = fresh_params()->timeline;\n"
 EXIT_NEW = (EXIT_OLD +
             "    if (tl != nullptr && lane == 0 && blockIdx.x < %dU)\n"
-            "        tl[2u + blockIdx.x * %du + wave] = (__builtin_amdgcn_s_memrealtime() << 4) | (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u);\n") % (MAXG, WAVES)
+            "        { tl[2u + blockIdx.x * %du + wave] = (__builtin_amdgcn_s_memrealtime() << 4) | (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u);\n"
+            "          tl[2u + %du + blockIdx.x * %du + wave] = __builtin_amdgcn_s_memtime(); }\n") % (MAXG, WAVES, 2 * MAXG * WAVES, WAVES)
 
 
 def build():
@@ -96,7 +98,7 @@ def run(a):
     for k in range(300):  # the chip's clock ramps over the first milliseconds
         launch(k)
     torch.cuda.synchronize()
-    n = 1 + MAXG * WAVES  # pair 0 = the launch's own {entry, exit}; then exits, then entries
+    n = 1 + 2 * MAXG * WAVES  # pair 0 = the launch's own {entry, exit}; then exits, entries (100 MHz clock), exits, entries (s_memtime)
     history = []  # per launch: each workgroup's mean wave exit minus the launch's mean (what a static re-deal could take out)
     for rep in range(a.launches):
         tl = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
@@ -111,6 +113,8 @@ def run(a):
         t_in, t_out = int(raw[0]), int(raw[1])
         ex = raw[2:2 + MAXG * WAVES].reshape(MAXG, WAVES)
         en = raw[2 + MAXG * WAVES:2 + 2 * MAXG * WAVES].reshape(MAXG, WAVES)
+        mex = raw[2 + 2 * MAXG * WAVES:2 + 3 * MAXG * WAVES].reshape(MAXG, WAVES)
+        men = raw[2 + 3 * MAXG * WAVES:2 + 4 * MAXG * WAVES].reshape(MAXG, WAVES)
         used = (ex != 0).any(axis=1)
         G = int(used.sum())
         xcc = (ex[used] & np.uint64(15)).astype(np.int64)
@@ -129,6 +133,11 @@ def run(a):
             rows.append((x, int(m.sum()), e[m].mean(), wg_last[m].max(), wg_mean[m].min(), wg_mean[m].max()))
         print("   per XCD (id, workgroups, mean wave exit, last exit, slowest/fastest workgroup mean): " + "; ".join(f"{x}: {c} {me:.2f} {la:.2f} [{lo:.2f},{hi:.2f}]" for x, c, me, la, lo, hi in rows))
         xm = np.array([r[2] for r in rows])
+        # s_memtime ticks per 100 MHz tick over a wave's life, by XCD: do the XCDs run at one clock?
+        dt_real = ((ex[used] >> np.uint64(4)).astype(np.int64) - en[used].astype(np.int64)).astype(np.float64)
+        dt_mem = (mex[used].astype(np.int64) - men[used].astype(np.int64)).astype(np.float64)
+        ratio = dt_mem / np.maximum(dt_real, 1.0)
+        print("   s_memtime ticks per 100 MHz tick over a wave's life, per XCD: " + " ".join(f"{x}: {ratio[xcc == x].mean():.3f}" for x in sorted(set(xcc.tolist()))))
         history.append(wg_mean - e.mean())
         print(f"   if waves could be balanced ... inside a workgroup: launch ends at {wg_mean.max():.2f}; inside an XCD: {xm.max():.2f}; over the chip: {e.mean():.2f} (now {e.max():.2f}); "
               f"spread of XCD means {xm.max() - xm.min():.2f} us")
