@@ -426,7 +426,7 @@ def main():
     light_bytes = light_only_bytes + (hzb_bytes if rides else 0)
     # ... counting the depth buffer ONCE: the riding chain's read of it is the launch's second (the tile DMA has fetched the
     # same rows for the sky test), so the launch's compulsory bytes are smaller by one depth buffer
-    light_bytes_dedup = light_bytes - (4 * W * band if (rides and N == 1) else 0)
+    light_bytes_dedup = light_bytes - (4 * W * band if rides else 0)  # (at N > 1: the rows of this rank's band)
     light_avg_s = float(light_ms.mean()) * 1e-3        # dispatch begin -> end, averaged over the samples of the timed region
     bracket_avg_s = float(bracket_ms.mean()) * 1e-3    # secondary: [record, launch, record] of the untimed frames behind it
     record_avg_s = float(record_ms.mean()) * 1e-3
