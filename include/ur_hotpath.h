@@ -150,6 +150,10 @@ int ur_flush(ur_ctx* ctx);
  * the Lighting launch, see UR_ETIMEOUT): the next ur_flush / ur_build_hzb / ur_cull_indirect_args* / ur_frame_render on the
  * context returns UR_ETIMEOUT once. For tests of the host's error path. */
 int ur_debug_set_hzb_timeout(ur_ctx* ctx);
+/* Debug: the tile schedule of the context's last streaming Lighting launch: out8 = {lighting workgroups, tiles, tiles dealt
+ * statically, chunks claimed at run time (0: balancing off for that launch), log2 of the tiles per chunk, chunks claimed ahead,
+ * waves per workgroup, Build HZB pieces that rode along}. All zero before the first such launch. */
+int ur_debug_lighting_schedule(const ur_ctx* ctx, uint32_t out8[8]);
 /* Debug: a GPU-side timeline of the context's launches. device_pairs: capacity_pairs x 2 uint64 in device memory, every pair
  * initialised by the caller to {~0, 0}. From then on each cull launch and each streaming Lighting launch on the context takes
  * the next pair (until the array is full) and folds the constant 100 MHz clock (s_memrealtime) into it: [0] = first workgroup's entry, [1] = last
@@ -167,13 +171,33 @@ int ur_debug_timeline(ur_ctx* ctx, unsigned long long* device_pairs, uint32_t ca
  * has to go out in front is not timed). The reference's counterpart is the timestamp-query pair FRenderGraph puts around a
  * pass (Source/Render/RenderGraph.cpp:402-406,475-478). NULL, NULL clears what was not consumed. */
 int ur_time_next_lighting(ur_ctx* ctx, void* start_event, void* stop_event);
-/* The same for the cull: the LAST launch of the next ur_cull_indirect_args* call on the context that is a single workgroup or writes
- * the visible list carries stop_event on its dispatch (its completion stamp). With the Lighting launch directly behind that cull on
+/* The same for the cull: the LAST launch of the next ur_cull_indirect_args* call on the context (the compaction launch when there
+ * is a visible list and more than 256 instances, the cull launch otherwise, the one-thread zeroing of visible_count when there are
+ * no instances) carries stop_event on its dispatch (its completion stamp). With the Lighting launch directly behind that cull on
  * the stream — the frame of ur_frame_render with UR_FRAME_HZB_WITH_LIGHTING is exactly those two launches — this event is the START
  * of the Lighting measurement and ur_time_next_lighting(ctx, NULL, stop) its end: hipEventElapsedTime(cull_stop, lighting_stop) is the
  * same interval as the marker form measures (end of what precedes the kernel -> end of the kernel) with NOTHING added to the queue.
- * One-shot; NULL clears an event that was not consumed (a words-only cull of several workgroups, or one of zero instances, takes none). */
+ * One-shot: that call clears it whether or not a dispatch took it (ur_time_cull_carried tells); NULL clears it beforehand. */
 int ur_time_next_cull(ur_ctx* ctx, void* stop_event);
+/* 1 if the last ur_cull_indirect_args* call on the context put the event of ur_time_next_cull on one of its dispatches, 0 if it
+ * launched nothing to carry it (zero instances and no visible_count). The call clears the pending event either way. */
+int ur_time_cull_carried(const ur_ctx* ctx);
+
+/* Launch-shape options, per context (two contexts of one process may differ; nothing is read from the environment). Every
+ * option keeps the results bit for bit: they choose between kernels / work splits that the parity tests hold to the same values.
+ * ur_set_option returns UR_EINVAL for an unknown option or a value outside the range given here. */
+#define UR_OPT_LIGHTING_STREAM 1        /* [1] 1 = streaming lighting kernel where it applies, 0 = always the per-tile kernel */
+#define UR_OPT_LIGHTING_WAVES_PER_WG 2  /* [16] waves per persistent workgroup of the streaming kernel: 16 (4 per SIMD) or 12 (3) */
+#define UR_OPT_LIGHTING_TILED_WAVES 3   /* [6] register budget of the per-tile kernel, in waves per SIMD: 6 (80 VGPRs) or 4 (uncapped) */
+#define UR_OPT_LIGHTING_LEAVE_CUS 4     /* [0] CUs the persistent lighting workgroups leave to kernels of other streams, 0..128 */
+#define UR_OPT_RIDE_WALKERS 5           /* [0] riding Build HZB chain: 0 = chosen per launch, 1 = one wave per workgroup walks the pieces, 16 = all */
+#define UR_OPT_CULL_STORE 7             /* [2] InstanceCount word stores: 2 = write-through (sc1), 1 = nontemporal, 0 = plain */
+#define UR_OPT_LIGHTING_BALANCE 8       /* [1] 1 = the last part of a streaming launch's tiles is claimed by the workgroups at run time
+                                           (inter-workgroup balancing), 0 = every tile dealt statically */
+#define UR_OPT_BALANCE_POOL_16THS 9     /* [3] that part, in sixteenths of the launch's tiles, 1..8 */
+#define UR_OPT_BALANCE_CHUNK_SHIFT 10   /* [4] log2 of the tiles per run-time claim, 2..6 */
+int ur_set_option(ur_ctx* ctx, int option, int value);
+int ur_get_option(const ur_ctx* ctx, int option, int* value);
 const char* ur_last_error(void);
 const char* ur_version(void);
 

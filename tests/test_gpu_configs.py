@@ -5,10 +5,8 @@ size-independent properties (band split == whole frame, every pixel finite, alph
   C4  pica_pica 3840x2160 screen-tiled 8 ways (the camera / light of Assets/Scenes/pica_pica.json)
   C5  1 M instance AABBs culled against the 12-mip HZB that ur_build_hzb makes from a 7680x4320 depth, and the 8K G-buffer lit
 plus the kernel instantiations no other test reaches: IRR_LDS = false (the irradiance mip is larger than 2x2, so it is
-gathered from memory instead of LDS) and the 12-waves-per-workgroup build (UR_LIGHTING_WPB=12, read once per process)."""
-import os
-import subprocess
-import sys
+gathered from memory instead of LDS) and the 12-waves-per-workgroup build (ur_set_option)."""
+
 from pathlib import Path
 
 import numpy as np
@@ -172,50 +170,30 @@ def test_every_irradiance_table_form(hotpath, oracle, fused, shadows, env_mip_co
         assert nbad == 0, (nbad, worst)
 
 
-_CHILD = """
-import numpy as np, sys, torch
-sys.path.insert(0, %(root)r)
-from tests.test_gpu_parity import _lighting_inputs, _device_tables
-from unclerenderer_amd import hostmath, synth
-from unclerenderer_amd.hotpath import HotPath, to_device
-hp = HotPath(0)
-out = {}
-for name, (w, h, mips) in {"lds": (320, 180, 6.0), "lds2": (320, 180, 5.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
-    fc, g, shadow, env, lut = _lighting_inputs('sponza', w, h, seed=33, mode='scene')
-    fc.scene.EnvMapMipCount = mips
-    tables = _device_tables(hp, shadow, env, lut)
-    for fused in (0, 1):
-        hdr = to_device(g.hdr)
-        if fused:
-            hp.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, hdr, w, h)
-        else:
-            hp.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, hdr, w, h)
-        torch.cuda.synchronize()
-        out[f"{name}{fused}"] = hdr.cpu().numpy().view(np.uint16)
-np.savez(%(dst)r, **out)
-"""
-
-
-def test_twelve_wave_workgroups_give_the_same_bits(hotpath, tmp_path):
-    """UR_LIGHTING_WPB=12 (3 waves per SIMD) runs the same arithmetic on a different work split: bit-identical output to the
-    default 16-wave build, for the LDS and the gathered irradiance, fused and not, and with partial tile rows."""
+def test_twelve_wave_workgroups_give_the_same_bits(hotpath):
+    """UR_OPT_LIGHTING_WAVES_PER_WG = 12 (3 waves per SIMD) runs the same arithmetic on a different work split: bit-identical
+    output to the default 16-wave build, for the LDS and the gathered irradiance, fused and not, and with partial tile rows.
+    Both builds run in this process, on one context (ur_set_option)."""
     import torch
     from tests.test_gpu_parity import _device_tables, _lighting_inputs
+    from unclerenderer_amd import lib
     from unclerenderer_amd.hotpath import to_device
-    dst = tmp_path / "wpb12.npz"
-    code = _CHILD % dict(root=str(Path(__file__).resolve().parent.parent), dst=str(dst))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UR_LIGHTING_WPB="12"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    child = np.load(dst)
-    for name, (w, h, mips) in {"lds": (320, 180, 6.0), "lds2": (320, 180, 5.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
-        fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=33, mode="scene")
-        fc.scene.EnvMapMipCount = mips
-        tables = _device_tables(hotpath, shadow, env, lut)
-        for fused in (0, 1):
-            hdr = to_device(g.hdr)
-            if fused:
-                hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, hdr, w, h)
-            else:
-                hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, hdr, w, h)
-            torch.cuda.synchronize()
-            assert np.array_equal(hdr.cpu().numpy().view(np.uint16), child[f"{name}{fused}"]), (name, fused)
+    try:
+        for name, (w, h, mips) in {"lds": (320, 180, 6.0), "lds2": (320, 180, 5.0), "mem": (320, 180, 3.0), "partial": (272, 33, 6.0)}.items():
+            fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=33, mode="scene")
+            fc.scene.EnvMapMipCount = mips
+            tables = _device_tables(hotpath, shadow, env, lut)
+            for fused in (0, 1):
+                got = {}
+                for wpb in (16, 12):
+                    hotpath.set_option(lib.UR_OPT_LIGHTING_WAVES_PER_WG, wpb)
+                    hdr = to_device(g.hdr)
+                    if fused:
+                        hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, hdr, w, h)
+                    else:
+                        hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, hdr, w, h)
+                    torch.cuda.synchronize()
+                    got[wpb] = hdr.cpu().numpy().view(np.uint16)
+                assert np.array_equal(got[16], got[12]), (name, fused)
+    finally:
+        hotpath.set_option(lib.UR_OPT_LIGHTING_WAVES_PER_WG, 16)

@@ -297,41 +297,30 @@ def test_lighting_shadow_border_and_outside(hotpath, oracle):
     assert (~fragile.astype(bool)).sum() > 0.9 * w * h
 
 
-def test_streaming_and_per_tile_kernels_agree(hotpath, oracle, tmp_path):
+def test_streaming_and_per_tile_kernels_agree(hotpath, oracle):
     """The two lighting kernels are independent implementations of the same pass (the per-tile one serves sky-only launches
     and the configurations the streaming kernel declines): on the same inputs EACH is within the HDR tolerance of the
     oracle on every pixel that is not shadow-compare fragile, hence they are within twice that of each other.
-    The per-tile kernel runs in a child process (UR_LIGHTING_STREAM is read once per process)."""
-    import os
-    import subprocess
-    import sys
+    The per-tile kernel is selected on the same context with ur_set_option(UR_OPT_LIGHTING_STREAM, 0)."""
     from tests.util import fp16_ulp, half_to_f32
+    from unclerenderer_amd import lib
     from unclerenderer_amd.hotpath import to_device
     torch = _torch()
     w, h = 320, 180
     fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=33, mode="scene")
     tables = _device_tables(hotpath, shadow, env, lut)
-    out = to_device(g.hdr)
-    hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, out, w, h)
-    torch.cuda.synchronize()
-    stream_bits = out.cpu().numpy().view(np.uint16)
-    child = tmp_path / "per_tile.npy"
-    code = (
-        "import numpy as np, torch, sys\n"
-        "sys.path.insert(0, %r)\n"
-        "from tests.test_gpu_parity import _lighting_inputs, _device_tables\n"
-        "from unclerenderer_amd.hotpath import HotPath, to_device\n"
-        "hp = HotPath(0)\n"
-        "fc, g, shadow, env, lut = _lighting_inputs('sponza', %d, %d, seed=33, mode='scene')\n"
-        "tables = _device_tables(hp, shadow, env, lut)\n"
-        "out = to_device(g.hdr)\n"
-        "hp.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, out, %d, %d)\n"
-        "torch.cuda.synchronize()\n"
-        "np.save(%r, out.cpu().numpy().view(np.uint16))\n"
-    ) % (str(__import__("pathlib").Path(__file__).resolve().parent.parent), w, h, w, h, str(child))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UR_LIGHTING_STREAM="0"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    tile_bits = np.load(child)
+    bits = {}
+    try:
+        for name, stream in (("streaming", 1), ("per-tile", 0)):
+            hotpath.set_option(lib.UR_OPT_LIGHTING_STREAM, stream)
+            assert hotpath.get_option(lib.UR_OPT_LIGHTING_STREAM) == stream
+            out = to_device(g.hdr)
+            hotpath.deferred_lighting_sky(fc.scene, fc.sky, to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth), tables, out, w, h)
+            torch.cuda.synchronize()
+            bits[name] = out.cpu().numpy().view(np.uint16)
+    finally:
+        hotpath.set_option(lib.UR_OPT_LIGHTING_STREAM, 1)
+    stream_bits, tile_bits = bits["streaming"], bits["per-tile"]
     lit, frag = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 32, 6, lut, g.hdr, w, h, want_fragile=True)
     ref = oracle.sky_atmosphere(fc.sky, g.depth, lit, w, h)
     for name, bits in (("streaming", stream_bits), ("per-tile", tile_bits)):

@@ -79,12 +79,12 @@ def test_streaming_kernels_have_no_scratch_and_no_spills(lighting_co):
     hot = next(v for k, v in meta.items() if HOT in k)
     # (an SGPR spill is a v_writelane / v_readlane pair, not scratch memory; the two the bench kernel has are written ahead of
     # the loop and read behind it: test_no_spill_traffic_inside_the_loop)
-    assert hot["private_segment_fixed_size"] == 0 and hot["vgpr_spill_count"] == 0 and hot["sgpr_spill_count"] <= 2, hot
+    assert hot["private_segment_fixed_size"] == 0 and hot["vgpr_spill_count"] == 0 and hot["sgpr_spill_count"] <= 4, hot
     assert hot["vgpr_count"] <= 128, hot  # 4 waves per SIMD need <= 128
     for name, m in meta.items():
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
         if "Li16ELb" in name:  # the shipped configuration (UR_LIGHTING_WPB=12 is a diagnostic one)
-            assert m["sgpr_spill_count"] <= 4 and m["vgpr_count"] <= 128, (name, m)
+            assert m["sgpr_spill_count"] <= 8 and m["vgpr_count"] <= 128, (name, m)  # (what the loop sees of them: test_no_spill_traffic_inside_the_loop)
 
 
 def _disassemble(co: Path, symbol_part: str) -> tuple[list[str], dict[str, int]]:
@@ -242,22 +242,35 @@ def _check_protocol(ins, labels, kernel):
         assert waits >= 1
 
 
-def test_no_spill_traffic_inside_the_loop(lighting_co):
-    """The persistent loop = everything between the target of a backward branch and that branch, for the shortest such span that
-    holds a tile DMA. No v_writelane / v_readlane (SGPR spill traffic) and no scratch access may sit in there."""
-    ins, labels = _disassemble(lighting_co, HOT)
+RIDE_ALL = "lighting_stream_kernelILi2ELb1ELb1ELi16ELb1E"  # the same kernel with every wave walking Build HZB pieces (short bands)
+
+
+@pytest.mark.parametrize("kernel", [HOT, RIDE_ALL, "lighting_stream_kernelILi0ELb1ELb1ELi16ELb0E"])
+def test_no_spill_traffic_inside_the_loop(lighting_co, kernel):
+    """The persistent loop's hot body = from the loop head (the lowest target of a backward branch that has a tile DMA inside its
+    span, the branches that span nearly the whole kernel aside) to the last such branch that starts at the head; the run-time
+    claim path (dyn_claim, cold) is laid out behind it and jumps back in. No SGPR-spill STORE (v_writelane) and no scratch access
+    anywhere on the cycle; no spill RELOAD (v_readlane) in the hot body of the bench kernel, at most two in the every-wave-walks
+    variant (one extra scalar of its pre-loop code lives across the loop)."""
+    ins, labels = _disassemble(lighting_co, kernel)
     dmas = [i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4")]
     loops = []
     for i, t in enumerate(ins):
         op = t.split()[0]
         if op.startswith(("s_cbranch", "s_branch")):
             tgt = labels.get(t.split()[-1])
-            if tgt is not None and tgt < i and any(tgt <= d <= i for d in dmas):
+            if tgt is not None and tgt < i and any(tgt <= d <= i for d in dmas) and i - tgt < len(ins) // 2:
                 loops.append((tgt, i))
     assert loops, "no backward branch around a tile DMA: where is the persistent loop?"
-    lo, hi = min(loops, key=lambda ab: ab[1] - ab[0])  # the innermost such loop is the persistent one
-    bad = [t for t in ins[lo:hi + 1] if t.startswith(("v_writelane", "v_readlane", "scratch_", "buffer_store", "buffer_load"))]
+    head = min(a for a, _ in loops)
+    body_end = max(b for a, b in loops if a == head)
+    cycle_end = max(b for _, b in loops)
+    assert body_end - head > 300, (head, body_end)  # the shading loop, not a sub-loop of it
+    spill_ops = ("v_writelane", "scratch_", "buffer_store", "buffer_load")
+    bad = [t for t in ins[head:cycle_end + 1] if t.startswith(spill_ops)]
     assert not bad, bad[:8]
+    reloads = [t for t in ins[head:body_end + 1] if t.startswith("v_readlane")]
+    assert len(reloads) <= (2 if kernel == RIDE_ALL else 0), reloads
 
 
 def test_the_product_kernel_source_carries_no_variant_switches():

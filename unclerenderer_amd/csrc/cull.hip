@@ -19,7 +19,6 @@
 
 #include <hip/hip_ext.h>
 
-#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -257,8 +256,7 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
     P.visible_idx = visible_idx;
     P.visible_count = visible_count;
     P.index_base = index_base;
-    static const int store_flavour = [] { const char* e = std::getenv("UR_CULL_STORE"); return e ? std::atoi(e) : 2; }();
-    P.store_flavour = (uint32_t)store_flavour;
+    P.store_flavour = (uint32_t)ctx->opt.cull_store; // UR_OPT_CULL_STORE
     P.timeline = P.ModelCount != 0 ? next_timeline_pair(ctx) : nullptr; // (the compaction launch of a large cull is not stamped)
     if (P.HZBEnabled != 0) {
         for (uint32_t m = 0; m < P.HZBMipCount && m < UR_MAX_HZB_MIPS; ++m) {
@@ -266,23 +264,26 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
             P.mip_width[m] = mips[m].width;
         }
     }
+    // ur_time_next_cull: the call's LAST launch carries the event on its dispatch (its completion stamp is somebody's start time).
+    // (ur_cull_indirect_args_ex clears the context's copy behind this function on every path: a raw hipEvent_t must not stay in
+    // the context for a later call.)
+    hipEvent_t stop = ctx->time_cull_stop;
     const uint32_t n = P.ModelCount;
     if (n == 0) {
         if (visible_count) {
-            hipLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, ctx->stream, visible_count);
+            if (stop != nullptr) hipExtLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, ctx->stream, nullptr, stop, 0, visible_count);
+            else hipLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, ctx->stream, visible_count);
             UR_HIP_TRY(hipGetLastError());
+            ctx->time_cull_carried = stop != nullptr;
         }
         return UR_OK;
     }
     const uint32_t blocks = (n + 255u) / 256u;
     if (blocks == 1) {
-        if (ctx->time_cull_stop != nullptr) { // ur_time_next_cull: this dispatch's completion stamp is somebody's start time
-            hipExtLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_cull_stop, 0, P);
-            ctx->time_cull_stop = nullptr;
-        } else {
-            hipLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, P);
-        }
+        if (stop != nullptr) hipExtLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, nullptr, stop, 0, P);
+        else hipLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, P);
         UR_HIP_TRY(hipGetLastError());
+        ctx->time_cull_carried = stop != nullptr;
         return UR_OK;
     }
     if (visible_idx) {
@@ -293,17 +294,15 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
         P.block_counts = ctx->block_counts;
         P.wave_masks = ctx->wave_masks;
     }
-    hipLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    if (stop != nullptr && !visible_idx) hipExtLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, nullptr, stop, 0, P);
+    else hipLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, P);
     UR_HIP_TRY(hipGetLastError());
     if (visible_idx) {
-        if (ctx->time_cull_stop != nullptr) { // (the call's LAST launch carries the event)
-            hipExtLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, nullptr, ctx->time_cull_stop, 0, P, blocks);
-            ctx->time_cull_stop = nullptr;
-        } else {
-            hipLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, P, blocks);
-        }
+        if (stop != nullptr) hipExtLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, nullptr, stop, 0, P, blocks);
+        else hipLaunchKernelGGL(compact_kernel, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, ctx->stream, P, blocks);
         UR_HIP_TRY(hipGetLastError());
     }
+    ctx->time_cull_carried = stop != nullptr;
     return UR_OK;
 }
 

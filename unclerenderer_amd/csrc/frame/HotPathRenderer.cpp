@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -224,6 +223,8 @@ ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, 
                 // dispatch directly in front of it when that is this frame's cull launch (ur_frame_render handed it the event: NOTHING
                 // enters the queue for the measurement), else a marker the runtime puts in front of the kernel (~8 us of queue time).
                 // (One event alone measures nothing on this runtime: hipEventElapsedTime(e, e) is 0.)
+                // (a cull call that launched nothing took no event: the marker form then, never a stamp left over from an earlier use of the slot)
+                if (f->bStartOnCull && !ur_time_cull_carried(f->Cmd.GetContext())) f->bStartOnCull = false;
                 (void)ur_time_next_lighting(f->Cmd.GetContext(), f->bStartOnCull ? nullptr : f->LightEvents[f->LightHead].first, f->LightEvents[f->LightHead].second);
             } else {
                 (void)ur_time_next_lighting(f->Cmd.GetContext(), nullptr, nullptr); // (a launch that failed validation consumed nothing)
@@ -319,7 +320,7 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     O.bAsyncCompute = (flags & UR_FRAME_ASYNC_COMPUTE) != 0;
     if (O.bAsyncCompute && !f->AsyncCtx) { // second stream + a context bound to it, created on first use
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithPriority(&f->AsyncStream, hipStreamNonBlocking, std::getenv("UR_ASYNC_PRIORITY") ? std::atoi(std::getenv("UR_ASYNC_PRIORITY")) : -1) != hipSuccess) return UR_EHIP; // default high priority: its short kernels slot in beside the lighting kernel
+        if (hipGetDevice(&dev) != hipSuccess || hipStreamCreateWithPriority(&f->AsyncStream, hipStreamNonBlocking, -1) != hipSuccess) return UR_EHIP; // high priority: its short kernels slot in beside the lighting kernel
         f->AsyncCtx = ur_create(dev, f->AsyncStream);
         if (!f->AsyncCtx) return UR_EHIP;
         f->Cmd.SetAsyncCompute(f->AsyncCtx, f->AsyncStream);
@@ -350,7 +351,7 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
             f->bStartOnCull = true;
     }
     const int rc = f->Renderer.RenderFrame(f->Cmd, R, K, O);
-    if (f->bStartOnCull) (void)ur_time_next_cull(f->Cmd.GetContext(), nullptr); // (a cull that launched nothing consumed nothing)
+    (void)ur_time_next_cull(f->Cmd.GetContext(), nullptr); // (a frame whose cull pass did not run consumed nothing)
     if (tail_with_lighting) {
         const int rc2 = ur_defer_hzb_tail(f->Cmd.GetContext(), 0); // launches the tail on its own if no Lighting launch took it
         // a riding tail that gave up waiting (a bounded wait inside an earlier Lighting launch) is reported here, once: UR_ETIMEOUT

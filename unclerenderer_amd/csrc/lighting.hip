@@ -28,7 +28,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
-#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -42,7 +41,8 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 struct StreamHot {
     uint32_t groups; // lighting workgroups of the launch (a workgroup with this index, if any, runs the deferred HZB tail)
     uint32_t tilesX, numTiles, tilesXMagic, W, rows, row0, irrN0, irrRowBytes; // tilesXMagic: tile / tilesX = (tile * magic) >> 32
-    uint32_t chunkShift; // log2 of the tiles a workgroup is dealt at a time
+    uint32_t staticClaims; // a workgroup's claims c < staticClaims are dealt statically (above); from there on they index the chunks the
+                           // workgroup claims at run time (Balance). 0xFFFFFFFF: every tile is dealt statically
     float invW2, invH2, invP11, nInvP22;      // ray: ra = ndc.x * invP11, rb = ndc.y * nInvP22 (= -1/P22)
     float skyInvP11, nSkyInvP22, skyNearOverR2, maxMip;
     float envMaxLevel, irrNf, irrEf, irrEEf, irrOfff; // irradiance mip: N, N+2, (N+2)^2, texel offset — as floats (exact)
@@ -60,6 +60,23 @@ struct StreamHot {
     float WA[3], WB[3], WC[3]; // world-space camera ray through the pixel = ndc.x * WA + ndc.y * WB + WC
     float lightRGB[3];
     float shA[3], shB[3], shC[3], shT[3]; // (su * W - 0.5, sv * H - 0.5, depth - bias)[k] = viewZ * (ndc.x * shA[k] + ndc.y * shB[k] + shC[k]) + shT[k]
+};
+
+// Inter-workgroup balancing of a streaming launch (UR_OPT_LIGHTING_BALANCE). Equal static shares leave the mean wave idle for the
+// last ~5 us of a 4K launch: XCDs differ by up to 8 % in speed on the same work (profiles/r03_wave_exit_stamps.txt). So only the tiles
+// [0, staticTiles) are dealt statically; the rest is a pool of chunks of 2^dynShift consecutive tiles that workgroups claim at run
+// time, one returning device-scope atomic per chunk, `lookahead` chunks ahead of use (the first `lookahead` of a workgroup are
+// pre-assigned). The pool is cut into kClaimWords sub-pools, word q serving workgroups 8q .. 8q+7 - one per XCD under round-robin
+// placement, which is what evens out the XCDs; any placement is correct. Per workgroup the claims are strictly sequential (the chunk
+// of slot k is claimed only after slot k - 1 has been published in LDS), so its slots are valid up to the first failed claim and
+// END from there on: exactly one failed claim per workgroup, after which it adds one to words[kClaimWords * stride]; the
+// workgroup whose add comes last puts every word back to zero for the next launch (also under hipGraph replay).
+struct Balance {
+    uint32_t poolChunks;   // 0: off
+    uint32_t staticTiles, dynShift, lookahead;
+    unsigned long long poolMagic; // first chunk of the share of workgroups [0, x) = (x * poolMagic) >> 32 (= x * poolChunks / groups, rounded up)
+    uint32_t* words;
+    uint32_t* timedOut;    // host-visible (mapped, coherent): a wave gave up waiting for a slot of its workgroup (ur_ctx::claim_timed_out)
 };
 
 struct LightingParams {
@@ -94,6 +111,7 @@ struct LightingParams {
     float skyMie[3];     // LightColor * mieDensity * 0.8 * (1-g^2)/(4 pi)
     float sunAttenuation;
     StreamHot hot;       // streaming kernel: everything one loop iteration reads
+    Balance bal;         // ... and what its run-time tile claims read (cold)
     unsigned long long* timeline; // debug: {first entry, last exit} of this launch (ur_debug_timeline), else null
     // buffers
     const half4_t* A;
@@ -574,12 +592,17 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
 //  * The shadow transform of the (orthographic) light is folded on the host into three affine forms of the camera ray.
 // =====================================================================================================================
 constexpr uint32_t kLutW = 128, kLutH = 32, kLutE = kLutW + 2;    // streaming kernel: LUT dimensions are compile-time
+constexpr uint32_t kChunkShift = 2;                                 // static deal: chunks of 4 consecutive tiles (4K, round 1: chunks of 16 / 4 / 1 tiles -> 75.4 / 74.6 / 79.1 us)
 constexpr uint32_t kLdsSrgb = 0;                                    // 256 floats
 constexpr uint32_t kLdsIrrBytes = 6 * 9 * 64;                       // 54 cells x 64 B
-constexpr uint32_t kLdsWork = 1024 + 17 * 32 + kLdsIrrBytes;        // [0] the workgroup's tile counter, [1] waves that left the loop (16 bytes reserved)
+constexpr uint32_t kLdsWork = 1024 + 17 * 32 + kLdsIrrBytes;        // [0] the workgroup's tile counter, [1] waves that left the loop, [2] HZB walkers done,
+                                                                    // [4] first run-time chunk of the workgroup's claim word, [5] how many follow (32 bytes reserved)
+constexpr uint32_t kDynSlots = 256;                                 // run-time chunk slots of a workgroup: tile index of the chunk's first tile, or:
+constexpr uint32_t kDynNotReady = 0xFFFFFFFFu, kDynEnd = 0xFFFF0000u; // not published yet / nothing left to claim (any value >= kDynEnd)
+constexpr uint32_t kLdsDyn = kLdsWork + 32;
 constexpr uint32_t kLdsMip = 1024;                                  // 17 x 16 B: per-mip cube constants (MipEntry)
 constexpr uint32_t kLdsIrr = 1024 + 17 * 32;                        // irradiance mip (N <= 2) as per-cell polynomials: up to 6 * 3 * 3 cells of 64 B
-constexpr uint32_t kLdsHzb = kLdsWork + 16;                         // 80 floats per wave: mip-2 / mip-3 scratch of the waves that walk HZB pieces
+constexpr uint32_t kLdsHzb = kLdsDyn + kDynSlots * 4;               // 80 floats per wave: mip-2 / mip-3 scratch of the waves that walk HZB pieces
 constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
@@ -731,6 +754,66 @@ __device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u
     asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d));
 }
 
+// ---- run-time tile claims (struct Balance) -----------------------------------------------------------------------------------------
+// One word of the workgroup's slot table, read by every lane (same address: a broadcast), as a scalar.
+__device__ __forceinline__ uint32_t dyn_slot_load(const uint32_t* slot)
+{
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+// ... waiting until it is published. The publisher is another wave of this workgroup that waits for nothing but memory, so the
+// wait ends; it is bounded all the same (~0.25 s of s_sleep), and giving up is reported (ur_ctx::claim_timed_out -> UR_ETIMEOUT).
+template <class P>
+__device__ __forceinline__ uint32_t dyn_slot_wait(const uint32_t* slot, P kp)
+{
+    uint32_t e = dyn_slot_load(slot), spins = 0;
+    while (e == kDynNotReady) {
+        __builtin_amdgcn_s_sleep(8);
+        e = dyn_slot_load(slot);
+        if (++spins > (1u << 21)) {
+            __hip_atomic_store(kp->bal.timedOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            e = kDynEnd;
+            break;
+        }
+    }
+    return e;
+}
+// Claim c >= staticClaims of the workgroup -> tile index (0xFFFFFFFF: nothing left). The wave that draws the first claim of slot s
+// also claims the chunk of slot s + lookahead from the workgroup's word and publishes it. It blocks for that one atomic (~1 us under
+// the launch's stream; its next tile is already in LDS), which happens once per 2^dynShift tiles of the WORKGROUP and only in the
+// last part of the launch. Called at the prefetch point: the wave has no vector-memory operation in flight.
+template <class P>
+__device__ __forceinline__ uint32_t dyn_claim(P kp, uint32_t* work, uint32_t* dynT, uint32_t c, uint32_t lane)
+{
+    const uint32_t d = c - kp->hot.staticClaims;
+    const uint32_t s = min(d >> kp->bal.dynShift, kDynSlots - 1u);
+    const uint32_t e = dyn_slot_wait(dynT + s, kp);
+    if (e >= kDynEnd) return 0xFFFFFFFFu;
+    const uint32_t idx = d & ((1u << kp->bal.dynShift) - 1u);
+    if (idx == 0u) { // uniform
+        const uint32_t k = s + kp->bal.lookahead;
+        if (k < kDynSlots) {
+            uint32_t out = kDynEnd;
+            // strictly one claim after the other: the slot in front must have been published (and still have had a chunk)
+            if (dyn_slot_wait(dynT + (k - 1u), kp) < kDynEnd && k + 1u < kDynSlots) {
+                uint32_t v = 0;
+                if (lane == 0) v = __hip_atomic_fetch_add(kp->bal.words + (blockIdx.x >> 3) * ur::kClaimWordStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = __builtin_amdgcn_readfirstlane(v);
+                if (v < dyn_slot_load(work + 5)) out = kp->bal.staticTiles + ((dyn_slot_load(work + 4) + v) << kp->bal.dynShift);
+                else {
+                    // this workgroup's last claim (every claim in front of it has returned): count it; the workgroup that
+                    // counts last puts the words back to zero, write-through, for the next launch
+                    uint32_t done = 0;
+                    if (lane == 0) done = __hip_atomic_fetch_add(kp->bal.words + ur::kClaimWords * ur::kClaimWordStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_readfirstlane(done) == kp->hot.groups - 1u && lane <= ur::kClaimWords)
+                        __hip_atomic_store(kp->bal.words + lane * ur::kClaimWordStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (lane == 0) __hip_atomic_store(dynT + k, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    return e + idx;
+}
+
 // WPB waves per workgroup, one workgroup per CU (two of 10 waves at 96 VGPRs were tried: the loop spills).
 // HDR stores are write-through (sc1): in a loop of its own the launch takes the same time as with plain or nontemporal stores, but
 // nothing of it is left dirty in L2 for the end of the launch to write back, and the NEXT launch of the frame starts 0.6-0.9 us
@@ -810,6 +893,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     float4a* irrT = reinterpret_cast<float4a*>(smem + kLdsIrr);
     float2* lut = reinterpret_cast<float2*>(smem + kLdsLut);
     uint32_t* work = reinterpret_cast<uint32_t*>(smem + kLdsWork);
+    uint32_t* dynT = reinterpret_cast<uint32_t*>(smem + kLdsDyn);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // uniform by construction: keeps the tile walk on the scalar ALU
@@ -841,7 +925,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     // arbitration lets some waves of a workgroup run up to twice as fast as others (measured with in-kernel stamps); with
     // a static split the slow ones set the kernel's duration, with the counter all of them finish together.
     // Claims c = wave and c = WPB + wave are static (the two tiles of the prologue).
-    const uint32_t cs = p.hot.chunkShift, chunkStride = p.hot.groups << cs, base = blockIdx.x << cs, cmask = (1u << cs) - 1u;
+    constexpr uint32_t cs = kChunkShift, cmask = (1u << cs) - 1u;
+    const uint32_t chunkStride = p.hot.groups << cs, base = blockIdx.x << cs;
     // claim c -> tile (c >> cs) * chunkStride + base + (c & cmask): chunks of 2^cs consecutive tiles, dealt round-robin
     uint32_t tile = (wave >> cs) * chunkStride + base + (wave & cmask);
     uint32_t tile1 = ((wave + WPB) >> cs) * chunkStride + base + ((wave + WPB) & cmask);
@@ -864,16 +949,26 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     const float negBig = vreg(-0x1p126f);
     // Launch constants of the FMA-dense parts as VGPR operands: two neighbouring VALU instructions that both read an SGPR
     // cannot share an issue slot (tools/microbench/valu_rate4.hip), and a VOP3 reads one SGPR at most.
-    float R[9], WC[3], shC[3], shT[3], lightRGB[3];
+    float R[9], WC[3], shC[3], shT[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = vreg(p.hot.R[k]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); shT[k] = vreg(p.hot.shT[k]); lightRGB[k] = vreg(p.hot.lightRGB[k]);
+        WC[k] = vreg(p.hot.WC[k]); shC[k] = vreg(p.hot.shC[k]); shT[k] = vreg(p.hot.shT[k]);
     }
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
         if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
+        if (p.bal.poolChunks != 0u && threadIdx.x < kDynSlots) { // uniform: the run-time part of the tile schedule (struct Balance)
+            // this workgroup's claim word q serves workgroups [8q, 8q + 8): its share of the pool is chunks [P0, P1); the first
+            // `lookahead` chunks of each of its nq workgroups are pre-assigned, the rest is claimed
+            const uint32_t q8 = blockIdx.x & ~7u, nq = min(8u, p.hot.groups - q8), j = blockIdx.x - q8, la = p.bal.lookahead;
+            const uint32_t P0 = (uint32_t)(((unsigned long long)q8 * p.bal.poolMagic) >> 32);
+            const uint32_t P1 = (uint32_t)(((unsigned long long)(q8 + nq) * p.bal.poolMagic) >> 32);
+            const uint32_t first = P0 + la * nq; // (the host has checked P1 - P0 >= la * nq for every word)
+            dynT[threadIdx.x] = threadIdx.x < la ? p.bal.staticTiles + ((P0 + j * la + threadIdx.x) << p.bal.dynShift) : kDynNotReady;
+            if (threadIdx.x == 0) { work[4] = first; work[5] = P1 - first; }
+        }
         if (threadIdx.x < 256u) srgb[threadIdx.x] = sv;
         if (threadIdx.x < irrCount) {
             // value(fx, fy) = t00 + (t10 - t00) fx + (t01 - t00) fy + (t11 - t10 - t01 + t00) fx fy, per channel
@@ -969,7 +1064,8 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 #define UR_PREFETCH_POINT()                                                                                              \
     do {                                                                                                                 \
         const uint32_t c = __builtin_amdgcn_readfirstlane(claim); /* 0 when nothing was claimed (more1 == 0) */            \
-        tile2 = (c >> cs) * chunkStride + base + (c & cmask);                                                            \
+        if (__builtin_expect(c >= p.hot.staticClaims, 0)) tile2 = dyn_claim(kp, work, dynT, c, lane); /* (uniform) */      \
+        else tile2 = (c >> cs) * chunkStride + base + (c & cmask);                                                       \
         uint32_t in_band;                                                                                                \
         asm("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(in_band) : "s"(tile2), "s"(p.hot.numTiles) : "scc"); \
         more2 = in_band & more1; /* scalar AND: no branch on more1 here */                                                \
@@ -1252,7 +1348,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 {                                                                                                         \
     const float F = fmaf(1.0f - F0c, p5, F0c);                                                            \
     const float direct = fmaf(F, scs - Ac, Ac);                                                           \
-    colc = fmaf(direct, lightRGB[i] * sh_l, colc);                                                        \
+    colc = fmaf(direct, p.hot.lightRGB[i] * sh_l, colc); /* (an SGPR operand: three registers the claim path needs) */ \
 }
                 UR_CHANNEL(F0xy.x, Axy.x, colxy.x, 0)
                 UR_CHANNEL(F0xy.y, Axy.y, colxy.y, 1)
@@ -1302,12 +1398,6 @@ void mat4_mul(const float* a, const float* b, float* o)
         }
 }
 
-int env_int(const char* name, int dflt)
-{
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
-}
-
 // One Lighting launch. With a pair of events waiting on the context (ur_time_next_lighting) the dispatch itself carries
 // them (hipExtLaunchKernelGGL): their distance is the kernel's own begin -> end interval, no event record in the queue.
 template <class K, class... Args>
@@ -1329,8 +1419,7 @@ void launch_tiled(ur_ctx* ctx, const LightingParams& p)
     constexpr int TW = 16; // pixels per wave = 16 x 4: 128-byte G-buffer row segments and compact gather footprints
     const uint32_t tilesX = (p.W + 4 * TW - 1) / (4 * TW), tilesY = (p.rows + (64 / TW) - 1) / (64 / TW);
     // register budget: waves/SIMD the kernel is compiled for (6 -> 80 VGPRs, the most that does not spill; 4 -> no cap)
-    static const int waves = env_int("UR_LIGHTING_WAVES", 6);
-    if (waves >= 6) launch_timed(ctx, lighting_kernel<MODE, SHADOWS, TW, 6>, dim3(tilesX, tilesY), dim3(256), 0u, p);
+    if (ctx->opt.tiled_waves >= 6) /* UR_OPT_LIGHTING_TILED_WAVES */ launch_timed(ctx, lighting_kernel<MODE, SHADOWS, TW, 6>, dim3(tilesX, tilesY), dim3(256), 0u, p);
     else launch_timed(ctx, lighting_kernel<MODE, SHADOWS, TW, 4>, dim3(tilesX, tilesY), dim3(256), 0u, p);
 }
 
@@ -1350,10 +1439,10 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     // A deferred HZB tail (ur_defer_hzb_tail) rides along as one extra 1024-thread workgroup on a CU of its own: the
     // lighting workgroups give up one CU (0.4 % of their throughput) and the frame saves a ~5 us single-workgroup launch.
     ur::HzbTail tail{};
-    // UR_LIGHTING_LEAVE_CUS = n leaves n CUs to kernels of other streams (the graph's async-compute passes): the persistent
+    // UR_OPT_LIGHTING_LEAVE_CUS = n leaves n CUs to kernels of other streams (the graph's async-compute passes): the persistent
     // workgroups otherwise fill every CU's register file and nothing runs beside them. Never below one lighting workgroup
     // (a CPX partition reports 32 CUs), and the tail is carried only when that still leaves the lighting a CU of its own.
-    static const int leave_env = std::min(std::max(env_int("UR_LIGHTING_LEAVE_CUS", 0), 0), 128);
+    const int leave_env = ctx->opt.leave_cus;
     const int cus = std::max(ctx->cu_count, 1);
     const int leave_cus = std::min(leave_env, cus - 1);
     const bool carry_tail = ctx->hzb_tail_pending && WPB == 16 && cus >= 16 && cus - leave_cus >= 2;
@@ -1370,7 +1459,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
             // walkers: the chain should be done within about a quarter of the shading (a piece is ~3 us of one wave's time, a
             // tile ~1.75 us): walkers >= 7 x pieces-per-workgroup / tiles-per-wave, rounded up to a power of two
             {
-                static const int forced = env_int("UR_RIDE_WALKERS", 0);
+                const int forced = ctx->opt.ride_walkers; // UR_OPT_RIDE_WALKERS
                 const uint32_t lighting_groups = std::max(1, cus - 1 - leave_cus);
                 const double per_group = (double)ride.pieces / lighting_groups, tiles_per_wave = (double)h.numTiles / (lighting_groups * WPB);
                 uint32_t wk = 1;
@@ -1388,14 +1477,47 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     h.groups = groups;
     // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
-    static const int chunk_shift = env_int("UR_LIGHTING_CHUNK_SHIFT", 2); // 4K: chunks of 16 / 4 / 1 tiles -> 75.4 / 74.6 / 79.1 us
-    h.chunkShift = (uint32_t)std::min(std::max(chunk_shift, 0), 4);
+    // ---- the run-time part of the schedule (struct Balance): whole rounds of the static deal in front, a pool of chunks behind
+    h.staticClaims = 0xFFFFFFFFu;
+    p.bal = Balance{};
+    if (ctx->opt.balance != 0 && ctx->claim_words != nullptr && groups >= 16u && groups <= 8u * ur::kClaimWords) {
+        constexpr uint32_t cs = kChunkShift;
+        const uint32_t round = groups << cs;
+        const uint32_t want_pool = (uint32_t)((uint64_t)h.numTiles * (uint32_t)ctx->opt.balance_pool_16ths / 16u);
+        for (uint32_t sh = (uint32_t)ctx->opt.balance_chunk_shift; sh >= 2u; --sh) { // smaller chunks for smaller launches
+            const uint32_t la = sh >= 4u ? 2u : (sh == 3u ? 3u : 4u); // chunks claimed ahead: a claim takes ~1 us, a chunk of 4 tiles lasts 0.5
+            const uint32_t rounds = (h.numTiles - want_pool) / round;
+            if ((rounds << cs) < 2u * (uint32_t)WPB) break; // (the two tiles of a wave's prologue are static claims)
+            const uint32_t static_tiles = rounds * round, chunks = (h.numTiles - static_tiles + (1u << sh) - 1u) >> sh;
+            if (chunks < (la + 2u) * groups) continue;
+            if ((uint64_t)chunks * 8u / groups + la + 8u > kDynSlots) break; // a workgroup's slot table would not hold its word's share
+            const unsigned long long magic = (((unsigned long long)chunks << 32) + groups - 1u) / groups;
+            bool ok = true;
+            for (uint32_t q8 = 0; q8 < groups && ok; q8 += 8u) {
+                const uint32_t nq = std::min(8u, groups - q8);
+                const uint32_t P0 = (uint32_t)((q8 * magic) >> 32), P1 = (uint32_t)(((q8 + nq) * magic) >> 32);
+                ok = P1 >= P0 + la * nq && P1 <= chunks;
+            }
+            if (!ok) continue;
+            h.staticClaims = rounds << cs;
+            p.bal.poolChunks = chunks; p.bal.staticTiles = static_tiles; p.bal.dynShift = sh; p.bal.lookahead = la;
+            p.bal.poolMagic = magic;
+            p.bal.words = ctx->claim_words;
+            p.bal.timedOut = ctx->claim_timed_out_dev;
+            break;
+        }
+    }
     const bool ride_all = ride.pieces != 0u && ride.walkers > 1u;
     const kernel_t kern = ride_all ? static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, true>)
                                    : static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, false>);
     if (dev < 0 || !attr_set[ride_all][dev]) {
         UR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0) attr_set[ride_all][dev] = true;
+    }
+    {
+        const uint32_t sched[8] = {groups, h.numTiles, p.bal.poolChunks != 0u ? p.bal.staticTiles : h.numTiles, p.bal.poolChunks, p.bal.dynShift, p.bal.lookahead,
+                                   (uint32_t)WPB, ride.pieces};
+        std::memcpy(ctx->last_schedule, sched, sizeof(sched));
     }
     launch_timed(ctx, kern, dim3(groups + (carry_tail ? 1u : 0u)), dim3(64 * WPB), lds, p, tail, ride);
     return UR_OK;
@@ -1406,8 +1528,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
 template <int MODE, bool SHADOWS, bool IRR_LDS>
 int launch_stream(ur_ctx* ctx, const LightingParams& p)
 {
-    static const int wpb = env_int("UR_LIGHTING_WPB", 16);
-    if (wpb == 12) return launch_stream_wpb<MODE, SHADOWS, IRR_LDS, 12>(ctx, p);
+    if (ctx->opt.lighting_wpb == 12) /* UR_OPT_LIGHTING_WAVES_PER_WG */ return launch_stream_wpb<MODE, SHADOWS, IRR_LDS, 12>(ctx, p);
     return launch_stream_wpb<MODE, SHADOWS, IRR_LDS, 16>(ctx, p);
 }
 
@@ -1524,7 +1645,7 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         return UR_EUNSUPPORTED;
     }
     // ---- streaming kernel when the band is a whole number of 16-pixel tile columns; the per-tile kernel otherwise -----------
-    static const int use_stream = env_int("UR_LIGHTING_STREAM", 1);
+    const int use_stream = ctx->opt.lighting_stream; // UR_OPT_LIGHTING_STREAM
     bool streamed = false;
     // (the streaming kernel addresses the staged cube in fp32: texel indices must stay below 2^24, i.e. base sizes up to 1024)
     uint64_t env_texels = 0;

@@ -30,6 +30,13 @@ namespace ur {
 
 int check_hzb_timeout(ur_ctx* ctx, const char* who)
 {
+    if (ctx && ctx->claim_timed_out && *ctx->claim_timed_out != 0u) {
+        *ctx->claim_timed_out = 0u;
+        (void)hipMemsetAsync(ctx->claim_words, 0, (kClaimWords + 1u) * kClaimWordStride * sizeof(uint32_t), ctx->stream);
+        set_error("%s: a wave of a balanced Lighting launch gave up waiting for a tile claim of its workgroup: tiles of that launch were not shaded — "
+                  "shade the frame again (reported once; the context is usable)", who);
+        return UR_ETIMEOUT;
+    }
     if (!ctx || !ctx->hzb_timed_out || *ctx->hzb_timed_out == 0u) return UR_OK;
     *ctx->hzb_timed_out = 0u;
     (void)hipMemsetAsync(ctx->hzb_done, 0, 64, ctx->stream); // stragglers may have left any count behind
@@ -116,7 +123,7 @@ typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStre
 extern "C" {
 
 const char* ur_last_error(void) { return ur::g_error; }
-const char* ur_version(void) { return "unclerenderer_amd hotpath 0.1 (gfx950)"; }
+const char* ur_version(void) { return "unclerenderer_amd hotpath 0.4 (gfx950)"; }
 
 ur_ctx* ur_create(int device, void* stream)
 {
@@ -163,6 +170,17 @@ ur_ctx* ur_create(int device, void* stream)
         ctx->hzb_timed_out = static_cast<volatile uint32_t*>(host);
         ctx->hzb_timed_out_dev = static_cast<uint32_t*>(devp);
         *ctx->hzb_timed_out = 0u;
+        ctx->claim_timed_out = ctx->hzb_timed_out + 1;
+        ctx->claim_timed_out_dev = ctx->hzb_timed_out_dev + 1;
+        *ctx->claim_timed_out = 0u;
+    }
+    {
+        const size_t bytes = (ur::kClaimWords + 1u) * ur::kClaimWordStride * sizeof(uint32_t);
+        if (hipMalloc(&ctx->claim_words, bytes) != hipSuccess || hipMemset(ctx->claim_words, 0, bytes) != hipSuccess) {
+            set_error("ur_create: tile-claim words allocation failed");
+            ur_destroy(ctx);
+            return nullptr;
+        }
     }
     if (ur_reserve(ctx, 1u << 20) != UR_OK) {
         ur_destroy(ctx);
@@ -179,6 +197,7 @@ void ur_destroy(ur_ctx* ctx)
     ctx->hzb_tail_pending = false;
     ctx->hzb_wide_pending = false;
     if (ctx->hzb_done) (void)hipFree(ctx->hzb_done);
+    if (ctx->claim_words) (void)hipFree(ctx->claim_words);
     if (ctx->hzb_timed_out) (void)hipHostFree(const_cast<uint32_t*>(ctx->hzb_timed_out));
     if (ctx->srgb_table) (void)hipFree(ctx->srgb_table);
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
@@ -217,6 +236,50 @@ int ur_time_next_cull(ur_ctx* ctx, void* stop_event)
 {
     if (!ctx) { set_error("ur_time_next_cull: null context"); return UR_EINVAL; }
     ctx->time_cull_stop = static_cast<hipEvent_t>(stop_event);
+    ctx->time_cull_carried = false; // (arming or clearing: nothing has carried THIS event)
+    return UR_OK;
+}
+
+int ur_time_cull_carried(const ur_ctx* ctx) { return ctx && ctx->time_cull_carried ? 1 : 0; }
+
+// option -> (field, lowest, highest, only these two values when `pair`)
+namespace {
+struct OptionSlot { int ur_ctx::Options::*field; int lo, hi; bool pair; };
+bool option_slot(int option, OptionSlot& o)
+{
+    typedef ur_ctx::Options O;
+    switch (option) {
+    case UR_OPT_LIGHTING_STREAM: o = {&O::lighting_stream, 0, 1, false}; return true;
+    case UR_OPT_LIGHTING_WAVES_PER_WG: o = {&O::lighting_wpb, 12, 16, true}; return true;
+    case UR_OPT_LIGHTING_TILED_WAVES: o = {&O::tiled_waves, 4, 6, true}; return true;
+    case UR_OPT_LIGHTING_LEAVE_CUS: o = {&O::leave_cus, 0, 128, false}; return true;
+    case UR_OPT_RIDE_WALKERS: o = {&O::ride_walkers, 0, 16, false}; return true;
+    case UR_OPT_CULL_STORE: o = {&O::cull_store, 0, 2, false}; return true;
+    case UR_OPT_LIGHTING_BALANCE: o = {&O::balance, 0, 1, false}; return true;
+    case UR_OPT_BALANCE_POOL_16THS: o = {&O::balance_pool_16ths, 1, 8, false}; return true;
+    case UR_OPT_BALANCE_CHUNK_SHIFT: o = {&O::balance_chunk_shift, 2, 6, false}; return true;
+    default: return false;
+    }
+}
+} // namespace
+
+int ur_set_option(ur_ctx* ctx, int option, int value)
+{
+    OptionSlot o;
+    if (!ctx || !option_slot(option, o)) { set_error("ur_set_option: unknown option %d", option); return UR_EINVAL; }
+    if (value < o.lo || value > o.hi || (o.pair && value != o.lo && value != o.hi)) {
+        set_error("ur_set_option: option %d takes %d%s%d, not %d", option, o.lo, o.pair ? " or " : " .. ", o.hi, value);
+        return UR_EINVAL;
+    }
+    ctx->opt.*(o.field) = value;
+    return UR_OK;
+}
+
+int ur_get_option(const ur_ctx* ctx, int option, int* value)
+{
+    OptionSlot o;
+    if (!ctx || !value || !option_slot(option, o)) { set_error("ur_get_option: unknown option %d", option); return UR_EINVAL; }
+    *value = ctx->opt.*(o.field);
     return UR_OK;
 }
 
@@ -226,6 +289,13 @@ int ur_flush(ur_ctx* ctx)
     const int trc = ur::check_hzb_timeout(ctx, "ur_flush");
     if (trc != UR_OK) return trc;
     return ur::flush_hzb_tail(ctx);
+}
+
+int ur_debug_lighting_schedule(const ur_ctx* ctx, uint32_t out8[8])
+{
+    if (!ctx || !out8) { set_error("ur_debug_lighting_schedule: null argument"); return UR_EINVAL; }
+    std::memcpy(out8, ctx->last_schedule, sizeof(ctx->last_schedule));
+    return UR_OK;
 }
 
 int ur_debug_set_hzb_timeout(ur_ctx* ctx)
@@ -281,9 +351,9 @@ int ur_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h
     return ur::launch_build_hzb(ctx, depth, src_w, src_h, hzb_base, mips, mip_count);
 }
 
-int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,
-                             const ur_mip_desc* mips, void* indirect_args, uint32_t* stats2, uint32_t* visible_idx,
-                             uint32_t* visible_count, uint32_t index_base)
+static int cull_checked(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,
+                        const ur_mip_desc* mips, void* indirect_args, uint32_t* stats2, uint32_t* visible_idx,
+                        uint32_t* visible_count, uint32_t index_base)
 {
     if (!ctx || !constants) { set_error("ur_cull_indirect_args: null ctx/constants"); return UR_EINVAL; }
     const uint32_t n = constants[40], hzb_on = constants[41], mipc = constants[42];
@@ -298,6 +368,16 @@ int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_fl
     const int trc = ur::check_hzb_timeout(ctx, "ur_cull_indirect_args");
     if (trc != UR_OK) return trc;
     return ur::launch_cull(ctx, constants, bounds, hzb_base, mips, indirect_args, stats2, visible_idx, visible_count, index_base);
+}
+
+int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,
+                             const ur_mip_desc* mips, void* indirect_args, uint32_t* stats2, uint32_t* visible_idx,
+                             uint32_t* visible_count, uint32_t index_base)
+{
+    if (ctx) ctx->time_cull_carried = false;
+    const int rc = cull_checked(ctx, constants, bounds, hzb_base, mips, indirect_args, stats2, visible_idx, visible_count, index_base);
+    if (ctx) ctx->time_cull_stop = nullptr; // one-shot whatever the call did (ur_time_next_cull)
+    return rc;
 }
 
 int ur_cull_indirect_args(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,

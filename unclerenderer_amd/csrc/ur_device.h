@@ -15,11 +15,11 @@ namespace ur {
 template <uint32_t BYTES>
 __device__ __forceinline__ void warm_kernarg()
 {
-    static_assert(BYTES < 13 * 64, "one load per line, 13 lines");
+    static_assert(BYTES < 16 * 64, "one load per line, 16 lines");
     constexpr uint32_t kLast = (BYTES / 64u) * 64u;
 #define UR_KA_LINE(i) ((i) * 64u < kLast ? (i) * 64u : kLast)
     auto k = __builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12;
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14, d15;
     if constexpr (kLast <= 3 * 64u) {
         asm volatile("s_load_dword %0, %4, %5\n\t"
                      "s_load_dword %1, %4, %6\n\t"
@@ -30,25 +30,26 @@ __device__ __forceinline__ void warm_kernarg()
                      : "s"(k), "n"(UR_KA_LINE(0)), "n"(UR_KA_LINE(1)), "n"(UR_KA_LINE(2)), "n"(UR_KA_LINE(3))
                      : "memory");
     } else {
-        asm volatile("s_load_dword %0, %13, %14\n\t"
-                     "s_load_dword %1, %13, %15\n\t"
-                     "s_load_dword %2, %13, %16\n\t"
-                     "s_load_dword %3, %13, %17\n\t"
-                     "s_load_dword %4, %13, %18\n\t"
-                     "s_load_dword %5, %13, %19\n\t"
-                     "s_load_dword %6, %13, %20\n\t"
-                     "s_load_dword %7, %13, %21\n\t"
-                     "s_load_dword %8, %13, %22\n\t"
-                     "s_load_dword %9, %13, %23\n\t"
-                     "s_load_dword %10, %13, %24\n\t"
-                     "s_load_dword %11, %13, %25\n\t"
-                     "s_load_dword %12, %13, %26\n\t"
+        asm volatile(
+                     "s_load_dword %0, %16, %17\n\t"
+                     "s_load_dword %1, %16, %18\n\t"
+                     "s_load_dword %2, %16, %19\n\t"
+                     "s_load_dword %3, %16, %20\n\t"
+                     "s_load_dword %4, %16, %21\n\t"
+                     "s_load_dword %5, %16, %22\n\t"
+                     "s_load_dword %6, %16, %23\n\t"
+                     "s_load_dword %7, %16, %24\n\t"
+                     "s_load_dword %8, %16, %25\n\t"
+                     "s_load_dword %9, %16, %26\n\t"
+                     "s_load_dword %10, %16, %27\n\t"
+                     "s_load_dword %11, %16, %28\n\t"
+                     "s_load_dword %12, %16, %29\n\t"
+                     "s_load_dword %13, %16, %30\n\t"
+                     "s_load_dword %14, %16, %31\n\t"
+                     "s_load_dword %15, %16, %32\n\t"
                      "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9),
-                       "=&s"(d10), "=&s"(d11), "=&s"(d12)
-                     : "s"(k), "n"(UR_KA_LINE(0)), "n"(UR_KA_LINE(1)), "n"(UR_KA_LINE(2)), "n"(UR_KA_LINE(3)), "n"(UR_KA_LINE(4)),
-                       "n"(UR_KA_LINE(5)), "n"(UR_KA_LINE(6)), "n"(UR_KA_LINE(7)), "n"(UR_KA_LINE(8)), "n"(UR_KA_LINE(9)),
-                       "n"(UR_KA_LINE(10)), "n"(UR_KA_LINE(11)), "n"(UR_KA_LINE(12))
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7), "=&s"(d8), "=&s"(d9), "=&s"(d10), "=&s"(d11), "=&s"(d12), "=&s"(d13), "=&s"(d14), "=&s"(d15)
+                     : "s"(k), "n"(UR_KA_LINE(0)), "n"(UR_KA_LINE(1)), "n"(UR_KA_LINE(2)), "n"(UR_KA_LINE(3)), "n"(UR_KA_LINE(4)), "n"(UR_KA_LINE(5)), "n"(UR_KA_LINE(6)), "n"(UR_KA_LINE(7)), "n"(UR_KA_LINE(8)), "n"(UR_KA_LINE(9)), "n"(UR_KA_LINE(10)), "n"(UR_KA_LINE(11)), "n"(UR_KA_LINE(12)), "n"(UR_KA_LINE(13)), "n"(UR_KA_LINE(14)), "n"(UR_KA_LINE(15))
                      : "memory");
     }
 #undef UR_KA_LINE

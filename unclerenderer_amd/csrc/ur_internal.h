@@ -11,6 +11,7 @@
 namespace ur {
 // Arguments of the single-workgroup tail of the HZB chain (csrc/hzb_tail.h): the levels from `first_mip` on.
 constexpr uint32_t kTailMaxLevels = 12, kTailTexels = 16384;
+constexpr uint32_t kClaimWords = 32, kClaimWordStride = 32; // (stride in uint32: 128 bytes)
 struct HzbTail {
     const float* src; // mip first_mip - 1 (global memory, written by the previous launch)
     uint32_t SW, SH, first_mip, levels;
@@ -53,7 +54,21 @@ struct ur_ctx {
     uint32_t* hzb_timed_out_dev = nullptr; // its device address
     // ur_time_next_lighting: events the next Lighting launch carries on its dispatch (hipExtLaunchKernel); consumed by it
     hipEvent_t time_start = nullptr, time_stop = nullptr;
-    hipEvent_t time_cull_stop = nullptr; // ur_time_next_cull: carried by the last launch of the next cull call that lists or is one block
+    hipEvent_t time_cull_stop = nullptr; // ur_time_next_cull: carried by the last launch of the next cull call, cleared by that call
+    bool time_cull_carried = false;      // ... and whether a dispatch of that call took it (ur_time_cull_carried)
+    // ur_set_option: launch-shape choices of this context (include/ur_hotpath.h, UR_OPT_*)
+    struct Options {
+        int lighting_stream = 1, lighting_wpb = 16, tiled_waves = 6, leave_cus = 0, ride_walkers = 0, cull_store = 2;
+        int balance = 1, balance_pool_16ths = 3, balance_chunk_shift = 4;
+    } opt;
+    // Inter-workgroup tile claims of the streaming lighting kernel (UR_OPT_LIGHTING_BALANCE): kClaimWords words, each on a 128-byte
+    // line of its own, + the count of workgroups that have made their last claim. All zero between launches: the workgroup whose
+    // last claim comes last zeroes them (csrc/lighting.hip).
+    uint32_t* claim_words = nullptr;
+    uint32_t last_schedule[8] = {}; // ur_debug_lighting_schedule: the tile schedule of the context's last streaming Lighting launch
+    // host-visible (mapped, coherent) word beside hzb_timed_out: a wave of a balanced launch gave up waiting for a claim
+    volatile uint32_t* claim_timed_out = nullptr;
+    uint32_t* claim_timed_out_dev = nullptr;
 };
 
 namespace ur {

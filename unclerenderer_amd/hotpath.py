@@ -73,6 +73,22 @@ class HotPath:
     def ctx(self):
         return self._ctx
 
+    def set_option(self, option: int, value: int):
+        """Launch-shape option of this context (lib.UR_OPT_*): results are the same bits under every value."""
+        _lib.check(self._L.ur_set_option(self._ctx, option, value), "ur_set_option")
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int(0)
+        _lib.check(self._L.ur_get_option(self._ctx, option, C.byref(v)), "ur_get_option")
+        return int(v.value)
+
+    def lighting_schedule(self) -> dict:
+        """Tile schedule of the last streaming Lighting launch on this context (ur_debug_lighting_schedule)."""
+        out = (C.c_uint32 * 8)()
+        _lib.check(self._L.ur_debug_lighting_schedule(self._ctx, out), "ur_debug_lighting_schedule")
+        keys = ("groups", "tiles", "static_tiles", "pool_chunks", "chunk_shift", "lookahead", "waves_per_wg", "hzb_pieces")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def reserve(self, max_instances: int):
         _lib.check(self._L.ur_reserve(self._ctx, max_instances), "ur_reserve")
 

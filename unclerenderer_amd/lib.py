@@ -23,6 +23,11 @@ UR_INDIRECT_COMMAND_STRIDE = 64
 UR_INDIRECT_INSTANCE_COUNT_OFFSET = 44
 
 
+# ur_set_option keys (include/ur_hotpath.h)
+UR_OPT_LIGHTING_STREAM, UR_OPT_LIGHTING_WAVES_PER_WG, UR_OPT_LIGHTING_TILED_WAVES, UR_OPT_LIGHTING_LEAVE_CUS, UR_OPT_RIDE_WALKERS = 1, 2, 3, 4, 5
+UR_OPT_CULL_STORE, UR_OPT_LIGHTING_BALANCE, UR_OPT_BALANCE_POOL_16THS, UR_OPT_BALANCE_CHUNK_SHIFT = 7, 8, 9, 10
+
+
 class MipDesc(C.Structure):
     _fields_ = [("offset", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -123,9 +128,13 @@ SIGNATURES = {
     "ur_defer_hzb_tail": (C.c_int, [_VP, C.c_int]),
     "ur_flush": (C.c_int, [_VP]),
     "ur_debug_set_hzb_timeout": (C.c_int, [_VP]),
+    "ur_debug_lighting_schedule": (C.c_int, [_VP, C.POINTER(_U32)]),
     "ur_debug_timeline": (C.c_int, [_VP, _VP, _U32]),
     "ur_time_next_lighting": (C.c_int, [_VP, _VP, _VP]),
     "ur_time_next_cull": (C.c_int, [_VP, _VP]),
+    "ur_time_cull_carried": (C.c_int, [_VP]),
+    "ur_set_option": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "ur_get_option": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int)]),
     "ur_last_error": (C.c_char_p, []),
     "ur_version": (C.c_char_p, []),
     "ur_hzb_layout": (_U32, [_U32, _U32, C.POINTER(MipDesc), C.POINTER(_U32)]),
