@@ -462,20 +462,31 @@ def main():
         "roofline": {
             "kernel": "lighting_stream_kernel<FUSED>" + (" carrying the Build HZB chain (wave pieces + tail workgroup)" if rides else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "timing": "HIP events carried on dispatches (hipExtLaunchKernel): end of the cull launch in front -> end of the Lighting launch, timed region",
+            # the same launch against its COMPULSORY bytes (the depth buffer counted once) and against what a plain streaming kernel of
+            # this byte count sustains on this box in this run (stream_ceiling_leg: four reads, one write, nothing computed)
+            "frac_dedup": light_bytes_dedup / light_avg_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch_dedup": light_bytes_dedup,
+            "stream_ceiling_GBps": None, "frac_of_stream_ceiling": None, "stream_ceiling_us": None,
             "bytes_per_launch": light_bytes, "avg_launch_us": light_avg_s * 1e6, "min_launch_us": float(light_ms.min()) * 1e3,
             "median_launch_us": float(np.median(light_ms)) * 1e3,
-            "bytes_per_launch_dedup": light_bytes_dedup, "frac_dedup": light_bytes_dedup / light_avg_s / 1e9 / HBM_PEAK_GBS,
-            "event_bracket_us": bracket_avg_s * 1e6, "event_record_us": record_avg_s * 1e6,
-            "frac_event_bracket": light_bytes / bracket_avg_s / 1e9 / HBM_PEAK_GBS if bracket_avg_s > 0 else None,
-            "frac_event_bracket_minus_record": light_bytes / (bracket_avg_s - record_avg_s) / 1e9 / HBM_PEAK_GBS if bracket_avg_s > record_avg_s else None,
+            "timing": "HIP events carried on dispatches (hipExtLaunchKernel): end of the cull launch in front -> end of the Lighting launch, timed region",
             "lighting_bytes": light_only_bytes, "hzb_bytes_in_launch": hzb_bytes if rides else 0,
             "frac_lighting_bytes_only": light_only_bytes / light_avg_s / 1e9 / HBM_PEAK_GBS,
             "shade_only_mpixels_per_s": g.depth.size * N / light_avg_s / 1e6,
             "launches_sampled": int(light_ms.size), "alone_on_stream_us": float(alone_ms.mean()) * 1e3,
             "alone_on_stream_frac": light_only_bytes / (float(alone_ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "event_bracket_us": bracket_avg_s * 1e6, "event_record_us": record_avg_s * 1e6,
+            "frac_event_bracket": light_bytes / bracket_avg_s / 1e9 / HBM_PEAK_GBS if bracket_avg_s > 0 else None,
+            "frac_event_bracket_minus_record": light_bytes / (bracket_avg_s - record_avg_s) / 1e9 / HBM_PEAK_GBS if bracket_avg_s > record_avg_s else None,
+            "schedule": hp.lighting_schedule(),
         },
     }
+    if rank == 0 and not args.no_extras:
+        # the practical ceiling, on this box, in this run, at this launch's byte count (untimed leg)
+        sc = stream_ceiling_leg(hp, torch, light_bytes, dev)
+        r_ = result["roofline"]
+        r_["stream_ceiling_GBps"], r_["stream_ceiling_us"] = sc["GBps"], sc["dispatch_us"]
+        r_["frac_of_stream_ceiling"] = achieved / sc["GBps"]
+        r_["stream_ceiling"] = sc
     traffic_file = ROOT / "profiles" / "traffic_latest.json"
     if traffic_file.exists():
         try:
@@ -500,6 +511,42 @@ def main():
         print(json.dumps(result))
     if N > 1:
         dist.destroy_process_group()
+
+
+def stream_ceiling_leg(hp, torch, nbytes, dev):
+    """The practical ceiling at this launch's byte count (untimed extras leg): a plain four-reads-one-write streaming kernel
+    (csrc/stream_ceiling.hip) moving `nbytes` per launch over three cold buffer sets of pseudo-random finite data, timed the way the
+    Lighting launch is: events carried on the dispatch (every 8th launch), and the back-to-back loop figure beside it."""
+    n16 = max(1, nbytes // (5 * 16))
+    ring = 3
+    gen = torch.Generator(device=f"cuda:{dev}")
+    gen.manual_seed(1234)
+    sets = []
+    for _ in range(ring):
+        ins = [(torch.randint(0, 0x3FFF, (n16 * 8,), dtype=torch.int16, device=f"cuda:{dev}", generator=gen) | 0x3000) for _ in range(4)]  # fp16 values in (0.125, 2)
+        sets.append((ins, torch.empty(n16 * 8, dtype=torch.int16, device=f"cuda:{dev}")))
+    for k in range(400):
+        hp.stream_ceiling(*sets[k % ring])
+    pairs = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    iters = 400
+    for k in range(iters):
+        if k % 8 == 0:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()  # (torch creates the HIP events at their first record)
+            pairs.append((a, b))
+            hp.stream_ceiling(*sets[k % ring], start=a, stop=b)
+        else:
+            hp.stream_ceiling(*sets[k % ring])
+    e1.record()
+    torch.cuda.synchronize()
+    loop_us = e0.elapsed_time(e1) * 1e3 / iters
+    disp_us = float(np.mean([a.elapsed_time(b) for a, b in pairs])) * 1e3
+    moved = n16 * 16 * 5
+    del sets
+    torch.cuda.empty_cache()
+    return {"bytes_per_launch": moved, "dispatch_us": disp_us, "loop_us": loop_us, "GBps": moved / disp_us / 1e3, "loop_GBps": moved / loop_us / 1e3}
 
 
 def _time_events(torch, fn, iters, warm=5):

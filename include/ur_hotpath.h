@@ -154,6 +154,13 @@ int ur_debug_set_hzb_timeout(ur_ctx* ctx);
  * statically, chunks claimed at run time (0: balancing off for that launch), log2 of the tiles per chunk, chunks claimed ahead,
  * waves per workgroup, Build HZB pieces that rode along}. All zero before the first such launch. */
 int ur_debug_lighting_schedule(const ur_ctx* ctx, uint32_t out8[8]);
+/* Measurement aid (no counterpart in the reference): a plain streaming kernel with the fused Lighting launch's byte mix and
+ * nothing to compute, out[i] = in0[i] + in1[i] + in2[i] + in3[i] on `elements16` 16-byte elements (device pointers, 16-byte
+ * aligned; four read streams, one write stream). What it sustains at a launch's byte count is the practical ceiling bench.py prints
+ * beside the roofline fraction (roofline.stream_ceiling_GBps). With events (hipEvent_t, timing enabled) the dispatch carries them
+ * like ur_time_next_lighting's: hipEventElapsedTime(start, stop) is the dispatch's duration. */
+int ur_debug_stream_ceiling(ur_ctx* ctx, const void* in0, const void* in1, const void* in2, const void* in3, void* out, uint64_t elements16,
+                            void* start_event, void* stop_event);
 /* Debug: a GPU-side timeline of the context's launches. device_pairs: capacity_pairs x 2 uint64 in device memory, every pair
  * initialised by the caller to {~0, 0}. From then on each cull launch and each streaming Lighting launch on the context takes
  * the next pair (until the array is full) and folds the constant 100 MHz clock (s_memrealtime) into it: [0] = first workgroup's entry, [1] = last

@@ -13,7 +13,7 @@ def _inputs(w, h, seed, mode="scene"):
     return _lighting_inputs("sponza", w, h, seed=seed, mode=mode)
 
 
-@pytest.mark.parametrize("w,h,pool,chunk", [(1920, 1080, 3, 4), (1920, 1080, 8, 2), (1280, 720, 8, 3), (2560, 1440, 3, 4), (2560, 1440, 6, 6), (1920, 1083, 4, 3)])
+@pytest.mark.parametrize("w,h,pool,chunk", [(1920, 1080, 3, 4), (1920, 1080, 8, 2), (1280, 720, 6, 3), (2560, 1440, 3, 4), (2560, 1440, 6, 6), (1920, 1083, 4, 3)])
 def test_balanced_schedule_gives_the_same_bits(hotpath, w, h, pool, chunk):
     import torch
     from tests.test_gpu_parity import _device_tables
@@ -78,7 +78,7 @@ def test_balanced_schedule_with_the_hzb_chain_riding_and_on_a_band(hotpath, orac
     try:
         for wpb in (16, 12):
             hotpath.set_option(lib.UR_OPT_LIGHTING_WAVES_PER_WG, wpb)
-            for row0, rows, pool in ((0, h, 3), (540, 540, 8), (0, 272, 8)):
+            for row0, rows, pool in ((0, h, 3), (540, 540, 6), (0, 272, 6)):  # (the last band is too short for a run-time part: static)
                 hotpath.set_option(lib.UR_OPT_LIGHTING_BALANCE, 0)
                 ref, _, _ = frame(row0, rows)
                 hotpath.set_option(lib.UR_OPT_LIGHTING_BALANCE, 1)
@@ -86,7 +86,7 @@ def test_balanced_schedule_with_the_hzb_chain_riding_and_on_a_band(hotpath, orac
                 hotpath.set_option(lib.UR_OPT_BALANCE_CHUNK_SHIFT, 2)
                 for k in range(3):
                     out, hzb, sched = frame(row0, rows)
-                    assert sched["pool_chunks"] > 0, (wpb, row0, rows, sched)
+                    assert (sched["pool_chunks"] > 0) == (rows >= 540), (wpb, row0, rows, sched)
                     if wpb == 16:
                         assert sched["hzb_pieces"] > 0, sched  # (the 12-wave build sends the chain out in front)
                     assert np.array_equal(out, ref), (wpb, row0, rows, k, sched)

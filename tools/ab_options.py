@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--gbuffer", default="scene")
     ap.add_argument("--no-frame", action="store_true")
+    ap.add_argument("--settle", type=int, default=1500, help="untimed launches / frames of a set in front of each of its measurements (the clock follows the load over milliseconds)")
     a = ap.parse_args()
     import torch
     from unclerenderer_amd import assets, hostmath, lib, synth
@@ -112,10 +113,10 @@ def main():
     for r in range(a.rounds):
         for name, opts in sets:
             apply(opts)
-            alone(40)
+            alone(a.settle)
             res[name]["alone"].append(alone(a.iters))
             if not a.no_frame:
-                frames(40)
+                frames(a.settle)
                 f, l = frames(a.iters)
                 res[name]["frame"].append(f)
                 res[name]["light"].append(l)

@@ -36,13 +36,18 @@ EXIT_NEW = (EXIT_OLD +
             "          tl[2u + %du + blockIdx.x * %du + wave] = __builtin_amdgcn_s_memtime(); }\n") % (MAXG, WAVES, 2 * MAXG * WAVES, WAVES)
 
 
+CLAIMS_OLD = "        ur::timeline_exit(tl, lane == 0 && left == WPB - 1u);\n"
+CLAIMS_NEW = (CLAIMS_OLD +
+              "        if (lane == 0 && left == WPB - 1u && blockIdx.x < %dU) tl[2u + %du + blockIdx.x] = work[0];\n") % (MAXG, 4 * MAXG * WAVES)
+
+
 def build():
     from unclerenderer_amd import build as b
     b.build()
     src = (b.CSRC / "lighting.hip").read_text()
-    assert src.count(ENTRY_OLD) == 1 and src.count(EXIT_OLD) == 1, "the product source moved: update the two anchors"
+    assert src.count(ENTRY_OLD) == 1 and src.count(EXIT_OLD) == 1 and src.count(CLAIMS_OLD) == 1, "the product source moved: update the anchors"
     tmp = b.CSRC / "_lighting_wavestamps.hip"
-    tmp.write_text(src.replace(ENTRY_OLD, ENTRY_NEW).replace(EXIT_OLD, EXIT_NEW))
+    tmp.write_text(src.replace(ENTRY_OLD, ENTRY_NEW).replace(EXIT_OLD, EXIT_NEW).replace(CLAIMS_OLD, CLAIMS_NEW))
     out = b.OUT / "variants"
     out.mkdir(parents=True, exist_ok=True)
     obj, lib = out / "lighting_wavestamps.o", out / "libur_wavestamps.so"
@@ -65,6 +70,7 @@ def run(a):
     from unclerenderer_amd import assets, hostmath, synth
     from unclerenderer_amd.hotpath import HotPath, HzbLayout, to_device
     hp = HotPath(0)
+    hp.set_option(8, a.balance)  # UR_OPT_LIGHTING_BALANCE
     W, H = a.width, a.height
     fc = hostmath.build_frame_constants("sponza", W, H)
     ad = ROOT / "tests" / "golden" / "assets"
@@ -98,7 +104,7 @@ def run(a):
     for k in range(300):  # the chip's clock ramps over the first milliseconds
         launch(k)
     torch.cuda.synchronize()
-    n = 1 + 2 * MAXG * WAVES  # pair 0 = the launch's own {entry, exit}; then exits, entries (100 MHz clock), exits, entries (s_memtime)
+    n = 1 + 2 * MAXG * WAVES + MAXG // 2  # (+ the workgroups' claim counts) pair 0 = the launch's own {entry, exit}; then exits, entries (100 MHz clock), exits, entries (s_memtime)
     history = []  # per launch: each workgroup's mean wave exit minus the launch's mean (what a static re-deal could take out)
     for rep in range(a.launches):
         tl = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
@@ -115,6 +121,7 @@ def run(a):
         en = raw[2 + MAXG * WAVES:2 + 2 * MAXG * WAVES].reshape(MAXG, WAVES)
         mex = raw[2 + 2 * MAXG * WAVES:2 + 3 * MAXG * WAVES].reshape(MAXG, WAVES)
         men = raw[2 + 3 * MAXG * WAVES:2 + 4 * MAXG * WAVES].reshape(MAXG, WAVES)
+        claims = raw[2 + 4 * MAXG * WAVES:2 + 4 * MAXG * WAVES + MAXG].astype(np.int64)
         used = (ex != 0).any(axis=1)
         G = int(used.sum())
         xcc = (ex[used] & np.uint64(15)).astype(np.int64)
@@ -133,6 +140,9 @@ def run(a):
             rows.append((x, int(m.sum()), e[m].mean(), wg_last[m].max(), wg_mean[m].min(), wg_mean[m].max()))
         print("   per XCD (id, workgroups, mean wave exit, last exit, slowest/fastest workgroup mean): " + "; ".join(f"{x}: {c} {me:.2f} {la:.2f} [{lo:.2f},{hi:.2f}]" for x, c, me, la, lo, hi in rows))
         xm = np.array([r[2] for r in rows])
+        cl = claims[used]
+        print(f"   tiles drawn per workgroup (LDS claim counter at exit; schedule {hp.lighting_schedule()}): min {cl.min()} median {int(np.median(cl))} max {cl.max()}; per XCD mean: "
+              + " ".join(f"{x}: {cl[xcc == x].mean():.1f}" for x in sorted(set(xcc.tolist()))))
         # s_memtime ticks per 100 MHz tick over a wave's life, by XCD: do the XCDs run at one clock?
         dt_real = ((ex[used] >> np.uint64(4)).astype(np.int64) - en[used].astype(np.int64)).astype(np.float64)
         dt_mem = (mex[used].astype(np.int64) - men[used].astype(np.int64)).astype(np.float64)
@@ -162,6 +172,7 @@ def main():
     ap.add_argument("--launches", type=int, default=5)
     ap.add_argument("--ride", action="store_true", help="carry the Build HZB chain in the launch (the bench default)")
     ap.add_argument("--cache", default="")
+    ap.add_argument("--balance", type=int, default=1, help="UR_OPT_LIGHTING_BALANCE for the run")
     a = ap.parse_args()
     if a.build:
         build()

@@ -35,6 +35,7 @@ SOURCES = [
     ("lighting.hip", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]),
     ("tonemap.hip", EXACT),
     ("taa.hip", EXACT),
+    ("stream_ceiling.hip", []),
     ("scene.cpp", ["-x", "hip"] + EXACT),
     ("dds.cpp", ["-x", "hip"] + EXACT),
     ("host_math.cpp", ["-x", "hip"] + EXACT),

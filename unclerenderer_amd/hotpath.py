@@ -118,6 +118,15 @@ class HotPath:
             _lib.check(self._L.ur_time_next_lighting(self._ctx, C.c_void_p(start.cuda_event) if start is not None else None, C.c_void_p(stop.cuda_event)),
                        "ur_time_next_lighting")
 
+    def stream_ceiling(self, ins, out, start: "torch.cuda.Event | None" = None, stop: "torch.cuda.Event | None" = None):
+        """out = ins[0] + ins[1] + ins[2] + ins[3] on 16-byte elements (ur_debug_stream_ceiling): the plain streaming kernel whose
+        rate bench.py prints as the practical ceiling. Events (recorded once before, like time_next_lighting's) ride on the dispatch."""
+        assert len(ins) == 4 and all(t.numel() * t.element_size() == out.numel() * out.element_size() for t in ins)
+        n16 = out.numel() * out.element_size() // 16
+        _lib.check(self._L.ur_debug_stream_ceiling(self._ctx, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]), _ptr(out), n16,
+                                                   C.c_void_p(start.cuda_event) if start is not None else None,
+                                                   C.c_void_p(stop.cuda_event) if stop is not None else None), "ur_debug_stream_ceiling")
+
     # ---- BuildHZB ----
     def build_hzb(self, depth: torch.Tensor, hzb: torch.Tensor, layout: HzbLayout):
         assert depth.dtype == torch.float32 and hzb.dtype == torch.float32 and hzb.numel() >= layout.total

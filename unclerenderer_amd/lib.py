@@ -129,6 +129,7 @@ SIGNATURES = {
     "ur_flush": (C.c_int, [_VP]),
     "ur_debug_set_hzb_timeout": (C.c_int, [_VP]),
     "ur_debug_lighting_schedule": (C.c_int, [_VP, C.POINTER(_U32)]),
+    "ur_debug_stream_ceiling": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
     "ur_debug_timeline": (C.c_int, [_VP, _VP, _U32]),
     "ur_time_next_lighting": (C.c_int, [_VP, _VP, _VP]),
     "ur_time_next_cull": (C.c_int, [_VP, _VP]),
