@@ -111,12 +111,15 @@ typedef struct ur_sky_constants {
 /* Read-only side tables of the lighting pass (t3..t5 of DeferredLighting.hlsl:11-16). All device. */
 typedef struct ur_lighting_tables {
     const float* shadow_map;       /* ShadowMapSize.x * ShadowMapSize.y R32F; may be NULL iff ShadowStrength <= 0 */
-    const ur_half4* env_cube;      /* bordered cube written by ur_stage_env_cube() */
+    const ur_half4* env_cube;      /* what ur_stage_env_cube() wrote: the bordered faces of every mip, then the same faces as row pairs */
     uint32_t env_base_size;        /* edge of mip 0 (256 for Assets/Textures/output_pmrem.dds) */
     uint32_t env_mip_count;        /* mips present in env_cube (9) */
     const uint16_t* brdf_lut_rg16; /* lut_width * lut_height texels, 2 x UNORM16 each (PreintegratedGF.dds) */
     uint32_t lut_width;            /* 128: NdotV axis */
     uint32_t lut_height;           /* 32: roughness axis */
+    uint64_t env_cube_texels;      /* ur_env_cube_texels(env_base_size, env_mip_count) as returned when env_cube was sized and staged: the
+                                      layout's tag. A buffer staged by another version of the library (round 2's layout had the bordered
+                                      faces only, a third of the size) is refused with UR_EINVAL instead of being read out of bounds */
 } ur_lighting_tables;
 
 /* ---- context ---------------------------------------------------------------------------------- */
@@ -202,7 +205,10 @@ int ur_time_cull_carried(const ur_ctx* ctx);
 #define UR_OPT_LIGHTING_BALANCE 8       /* [1] 1 = the last part of a streaming launch's tiles is claimed by the workgroups at run time
                                            (inter-workgroup balancing), 0 = every tile dealt statically */
 #define UR_OPT_BALANCE_POOL_16THS 9     /* [3] that part, in sixteenths of the launch's tiles, 1..8 */
-#define UR_OPT_BALANCE_CHUNK_SHIFT 10   /* [4] log2 of the tiles per run-time claim, 2..6 */
+#define UR_OPT_BALANCE_CHUNK_SHIFT 10   /* [4] log2 of the tiles per run-time claim, 2..6; a launch too short for a few such chunks per workgroup is dealt statically */
+#define UR_OPT_DEBUG_HZB_RIDE_STALL 11  /* [0] debug, the one option that DOES change results: 1 = the tail workgroup of a riding Build HZB chain expects
+                                           one arrival more than there are producers and gives up after ~1 ms, i.e. every riding launch takes the
+                                           real time-out path (UR_ETIMEOUT at the next entry point, stale small HZB levels) - for tests of that path */
 int ur_set_option(ur_ctx* ctx, int option, int value);
 int ur_get_option(const ur_ctx* ctx, int option, int* value);
 const char* ur_last_error(void);

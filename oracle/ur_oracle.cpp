@@ -816,7 +816,8 @@ void uro_sky_atmosphere(const ur_sky_constants* sky, const float* depth, ur_half
     });
 }
 
-// Bordered-cube reference layout (what ur_stage_env_cube must produce), computed from the folding rule.
+// Bordered-cube reference layout, computed from the folding rule: the FIRST section of what ur_stage_env_cube writes (the product
+// appends the same faces as row pairs behind it and sizes the whole with ur_env_cube_texels; tests compare section by section).
 size_t uro_env_cube_texels(uint32_t base, uint32_t mips)
 {
     size_t n = 0;

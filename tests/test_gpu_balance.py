@@ -13,7 +13,7 @@ def _inputs(w, h, seed, mode="scene"):
     return _lighting_inputs("sponza", w, h, seed=seed, mode=mode)
 
 
-@pytest.mark.parametrize("w,h,pool,chunk", [(1920, 1080, 3, 4), (1920, 1080, 8, 2), (1280, 720, 6, 3), (2560, 1440, 3, 4), (2560, 1440, 6, 6), (1920, 1083, 4, 3)])
+@pytest.mark.parametrize("w,h,pool,chunk", [(1920, 1080, 3, 2), (1920, 1080, 8, 2), (1280, 720, 6, 2), (2560, 1440, 6, 4), (2560, 1440, 8, 3), (1920, 1083, 6, 3), (3840, 2160, 3, 4)])
 def test_balanced_schedule_gives_the_same_bits(hotpath, w, h, pool, chunk):
     import torch
     from tests.test_gpu_parity import _device_tables

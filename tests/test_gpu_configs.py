@@ -197,3 +197,60 @@ def test_twelve_wave_workgroups_give_the_same_bits(hotpath):
                 assert np.array_equal(got[16], got[12]), (name, fused)
     finally:
         hotpath.set_option(lib.UR_OPT_LIGHTING_WAVES_PER_WG, 16)
+
+
+@pytest.mark.parametrize("d24", [False, True])
+def test_c1_duck_512_whole_frame(hotpath, oracle, d24):
+    """BASELINE config 1 at its own size, as ONE frame: Duck's camera, light (intensity 3: HDR values above 2.0, where the
+    tolerance is one fp16 ulp - SURVEY.md H6) and its one draw command (Assets/Scenes/Duck.json through csrc/scene.cpp), 512 x 512,
+    shipped IBL tables, driven through ur_frame_render twice: frame 1 culls on the frustum alone and builds the HZB, frame 2 culls
+    against it (DeferredRenderer.cpp:519,1210). HZB, InstanceCount words, visible list and counters bit-exact; the whole HDR frame
+    within max(1e-3, 1 ulp fp16). d24: the depth buffer quantised as the R24_UNORM_X8 SRV returns it (DeferredRenderer.cpp:3087-3096)."""
+    import torch
+    from unclerenderer_amd import hostmath, lib, scene, synth
+    from unclerenderer_amd.hotpath import Frame, HzbLayout, to_device
+    w = h = 512
+    fc = hostmath.build_frame_constants("duck", w, h, shadow_size=2048, env_mip_count=9)
+    assert fc.scene.LightIntensity == 3.0
+    g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, synth.SEED_BASE + 1)
+    depth = synth.quantize_d24(g.depth) if d24 else g.depth
+    if d24:
+        assert (depth != g.depth).any() and (depth[g.depth == 0] == 0).all()
+    shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+    env, lut, tables = _shipped_tables(hotpath, shadow)
+    sb = scene.load_scene_bounds(ASSETS / "Scenes" / "Duck.json")
+    assert sb.count == 1
+    lay = HzbLayout(w, h)
+    assert lay.count == 9  # 256^2 ... 1 (SURVEY.md a10)
+    dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(depth)
+    d_hzb = torch.zeros(lay.total, device="cuda")
+    args0 = synth.indirect_args_initial(1)
+    d_args, d_stats = to_device(args0), torch.zeros(2, dtype=torch.int32, device="cuda")
+    d_vis, d_cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, True)  # dwords 40-44 are filled by the frame
+    ref_hzb = np.nan_to_num(oracle.build_hzb(depth, lay.as_list(), lay.total))
+    lit, frag = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 256, 9, lut, g.hdr, w, h, want_fragile=True)
+    ref_hdr = oracle.sky_atmosphere(fc.sky, depth, lit, w, h)
+    assert (ref_hdr.view(np.float16).astype(np.float32)[..., :3] > 2.0).mean() > 0.01, "the fixture must reach the one-ulp branch of the tolerance"
+    frame = Frame(hotpath)
+    try:
+        for k, flags in enumerate((lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY,
+                                   lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY | lib.UR_FRAME_HZB_WITH_LIGHTING)):
+            hzb_on = k == 1  # the first frame has no HZB yet
+            assert frame.hzb_ready == hzb_on
+            d_args.copy_(to_device(args0)); d_stats.zero_()
+            hdr = to_device(g.hdr)
+            res = Frame.resources(w, h, 0, h, dA, dB, dC, dD, hdr, dD, d_hzb, lay, tables, to_device(sb.bounds), d_args, 1, 0, d_vis, d_cnt, d_stats)
+            frame.render(res, consts, fc.scene, fc.sky, flags)
+            torch.cuda.synchronize()
+            c = hostmath.pack_culling_constants(fc.view, fc.proj, 1, hzb_on, lay.count, lay.width, lay.height, True)
+            ref_args, ref_stats, ref_vis, ref_cnt = oracle.cull_indirect_args(c, sb.bounds, ref_hzb if hzb_on else None, lay.as_list(), args0)
+            assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args), k
+            assert int(d_cnt.cpu()[0]) == ref_cnt and np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt], ref_vis), k
+            assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats), k
+            assert np.array_equal(d_hzb.cpu().numpy().view(np.uint32), ref_hzb.view(np.uint32)), k
+            nbad, worst, _ = hdr_mismatch(hdr.cpu().numpy().view(np.uint16), ref_hdr, exclude=frag)
+            assert nbad == 0, (k, nbad, worst)
+        assert frag.mean() < 5e-3
+    finally:
+        frame.close()

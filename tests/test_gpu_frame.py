@@ -131,7 +131,7 @@ def test_lighting_timing_forms_leave_the_frame_alone(hotpath):
     consts = hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, True)
     base = lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY
 
-    def run(flags, frames=6):
+    def run(flags, frames=6, with_list=True):
         frame = Frame(hotpath)
         d_hzb = torch.zeros(lay.total, device="cuda")
         d_args, d_stats = to_device(args0), torch.zeros(2, dtype=torch.int32, device="cuda")
@@ -140,7 +140,8 @@ def test_lighting_timing_forms_leave_the_frame_alone(hotpath):
         for _ in range(frames):
             d_args.copy_(to_device(args0)); d_stats.zero_()
             hdr = to_device(g.hdr)
-            res = Frame.resources(w, h, 0, h, dA, dB, dC, dD, hdr, dD, d_hzb, lay, tables, bounds, d_args, n, 0, d_vis, d_cnt, d_stats)
+            res = Frame.resources(w, h, 0, h, dA, dB, dC, dD, hdr, dD, d_hzb, lay, tables, bounds, d_args, n, 0, d_vis if with_list else None,
+                                  d_cnt if with_list else None, d_stats)
             frame.render(res, consts, fc.scene, fc.sky, flags)
         torch.cuda.synchronize()
         times = frame.lighting_times_ms()
@@ -155,6 +156,13 @@ def test_lighting_timing_forms_leave_the_frame_alone(hotpath):
             assert t.size == 6 and (t > 0).all() and (t < 5.0).all(), (ride, timed, t)
             for a, b in zip(ref, out):
                 assert torch.equal(a, b), (ride, timed)
+    # more than 256 commands and NO visible list: the cull is one multi-workgroup launch, which carries the start event itself
+    # (round 3 left the event in the context on this path and the sample read a stale stamp)
+    ref, _ = run(base | lib.UR_FRAME_HZB_WITH_LIGHTING, with_list=False)
+    out, t = run(base | lib.UR_FRAME_HZB_WITH_LIGHTING | lib.UR_FRAME_TIME_LIGHTING_KERNEL, with_list=False)
+    assert t.size == 6 and (t > 0).all() and (t < 5.0).all(), t
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
 
     # the entry point itself: the pair rides on the next Lighting dispatch and is consumed by it
     hdr = to_device(g.hdr)
@@ -175,5 +183,27 @@ def test_lighting_timing_forms_leave_the_frame_alone(hotpath):
     L = hotpath._L
     import ctypes as C
     assert L.ur_time_next_lighting(hotpath._ctx, C.c_void_p(e0.cuda_event), None) == lib.UR_EINVAL
-    assert L.ur_time_next_cull(hotpath._ctx, None) in (lib.UR_OK, lib.UR_EINVAL)  # clearing is allowed or rejected, never a crash
+    assert L.ur_time_next_cull(hotpath._ctx, None) == lib.UR_OK  # NULL is the clearing form (include/ur_hotpath.h)
     hotpath.time_next_lighting(None, None)
+    # ur_time_next_cull is consumed or cleared by the very next cull call, whatever that call launches
+    c300 = hostmath.pack_culling_constants(fc.view, fc.proj, n, False, 0, 0, 0, False)
+    d_args = to_device(args0)
+    d_vis, d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    for label, cc, vis, cnt, carried in (("words only, two workgroups", c300, None, None, 1), ("with the list", c300, d_vis, d_cnt, 1),
+                                         ("no instances, count zeroed", hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, False), d_vis, d_cnt, 1),
+                                         ("no instances, nothing launched", hostmath.pack_culling_constants(fc.view, fc.proj, 0, False, 0, 0, 0, False), None, None, 0)):
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(); c1.record()
+        torch.cuda.synchronize()
+        assert L.ur_time_next_cull(hotpath._ctx, C.c_void_p(c0.cuda_event)) == lib.UR_OK
+        assert L.ur_time_cull_carried(hotpath._ctx) == 0
+        hotpath.cull_indirect_args(cc, bounds, None, None, d_args, None, vis, cnt)
+        assert L.ur_time_cull_carried(hotpath._ctx) == carried, label
+        hotpath.time_next_lighting(None, c1)
+        hotpath.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, hdr_b, w, h)
+        torch.cuda.synchronize()
+        if carried:
+            assert 0.0 < c0.elapsed_time(c1) < 5.0, label  # end of the cull call's last dispatch -> end of the Lighting dispatch
+        # the event did not stay behind: a second cull carries nothing
+        hotpath.cull_indirect_args(c300, bounds, None, None, d_args, None, None, None)
+        assert L.ur_time_cull_carried(hotpath._ctx) == 0, label

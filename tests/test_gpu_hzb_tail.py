@@ -434,3 +434,72 @@ def test_frame_render_reports_a_riding_tail_timeout(hotpath):
     frame.render(res, consts, fc.scene, fc.sky, flags)  # reported once
     torch.cuda.synchronize()
     frame.close()
+
+
+def test_the_kernel_side_of_a_riding_tail_timeout(hotpath):
+    """The REAL time-out path (round 3 tested only the host's half, through ur_debug_set_hzb_timeout): with
+    UR_OPT_DEBUG_HZB_RIDE_STALL the riding tail workgroup expects one arrival more than it has producers and gives up after ~1 ms.
+    It must raise the host-visible flag (UR_ETIMEOUT at the next entry point), leave the arrival word alone and mark the words
+    stale; riding launches queued BEFORE the host has noticed (their tails find a leftover count) report as well instead of passing
+    silently with a wrong HZB; and after the host's reset the same context rides correctly again."""
+    import torch
+    from unclerenderer_amd import lib
+    from unclerenderer_amd.hotpath import to_device
+    w, h = 1024, 512
+    fc, g, tables, lay, dev = _setup(hotpath, w, h)
+    ref_hzb, ref_hdr = _reference(hotpath, fc, g, tables, lay, dev, w, h)
+    L = lib.load()
+
+    def ride(n=1):
+        outs = []
+        hotpath.defer_hzb_tail(2)
+        try:
+            for _ in range(n):
+                hzb = torch.full((lay.total,), -1.0, device="cuda")
+                hdr = to_device(g.hdr)
+                # ur_build_hzb reports a time-out it finds: take the entry points apart from the checks with the raw calls
+                rc = L.ur_build_hzb(hotpath.ctx, dev["D"].data_ptr(), w, h, hzb.data_ptr(), lay.mips, lay.count)
+                outs.append((rc, hzb, hdr))
+                if rc == lib.UR_OK:
+                    hotpath.deferred_lighting_sky(fc.scene, fc.sky, dev["A"], dev["B"], dev["C"], dev["D"], tables, hdr, w, h)
+        finally:
+            L.ur_defer_hzb_tail(hotpath.ctx, 0)  # (its flush may itself report the time-out: the raw call does not raise)
+        torch.cuda.synchronize()
+        return outs
+
+    hotpath.set_option(lib.UR_OPT_DEBUG_HZB_RIDE_STALL, 1)
+    try:
+        (rc, hzb, hdr), = ride()
+        assert rc == lib.UR_OK
+        assert torch.equal(hdr, ref_hdr), "the shading itself is complete"
+        assert L.ur_flush(hotpath.ctx) == lib.UR_ETIMEOUT and b"gave up waiting" in L.ur_last_error()
+        assert L.ur_flush(hotpath.ctx) == lib.UR_OK
+    finally:
+        hotpath.set_option(lib.UR_OPT_DEBUG_HZB_RIDE_STALL, 0)
+    # stall again, then queue a NORMAL riding launch behind it before the host looks: its tail finds the words stale and reports
+    hotpath.set_option(lib.UR_OPT_DEBUG_HZB_RIDE_STALL, 1)
+    try:
+        hzb_a, hdr_a = torch.full((lay.total,), -1.0, device="cuda"), to_device(g.hdr)
+        hotpath.defer_hzb_tail(2)
+        assert L.ur_build_hzb(hotpath.ctx, dev["D"].data_ptr(), w, h, hzb_a.data_ptr(), lay.mips, lay.count) == lib.UR_OK
+        hotpath.deferred_lighting_sky(fc.scene, fc.sky, dev["A"], dev["B"], dev["C"], dev["D"], tables, hdr_a, w, h)
+        hotpath.set_option(lib.UR_OPT_DEBUG_HZB_RIDE_STALL, 0)
+        hzb_b, hdr_b = torch.full((lay.total,), -1.0, device="cuda"), to_device(g.hdr)
+        rc_b = L.ur_build_hzb(hotpath.ctx, dev["D"].data_ptr(), w, h, hzb_b.data_ptr(), lay.mips, lay.count)
+        if rc_b == lib.UR_OK:  # queued before the first launch's flag was seen (the usual case: the host runs ahead of the GPU)
+            hotpath.deferred_lighting_sky(fc.scene, fc.sky, dev["A"], dev["B"], dev["C"], dev["D"], tables, hdr_b, w, h)
+            torch.cuda.synchronize()
+            assert L.ur_flush(hotpath.ctx) == lib.UR_ETIMEOUT, "the launch behind a timed-out one must not pass silently"
+        else:
+            assert rc_b == lib.UR_ETIMEOUT
+        torch.cuda.synchronize()
+    finally:
+        hotpath.set_option(lib.UR_OPT_DEBUG_HZB_RIDE_STALL, 0)
+        L.ur_defer_hzb_tail(hotpath.ctx, 0)
+    while L.ur_flush(hotpath.ctx) == lib.UR_ETIMEOUT:  # (each report resets the words behind everything queued so far)
+        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    # clean again: three riding frames in a row give the reference bits
+    for rc, hzb, hdr in ride(3):
+        assert rc == lib.UR_OK and torch.equal(hzb, ref_hzb) and torch.equal(hdr, ref_hdr)
+    assert L.ur_flush(hotpath.ctx) == lib.UR_OK

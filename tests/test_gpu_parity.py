@@ -616,3 +616,82 @@ def test_cull_more_than_4096_blocks(hotpath, oracle):
     assert int(d_cnt.cpu()[0]) == ref_cnt and ref_cnt > 4096
     assert np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt], ref_vis)
     assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats)
+
+
+def test_lighting_view_ray_along_the_light(hotpath, oracle):
+    """A camera that looks straight into the light: around the frame's centre V.L -> -1 and |V + L|^2 = 2 + 2 V.L cancels (the
+    streaming kernel's algebraic half vector loses 1e-7 / (1 + V.L) of relative accuracy there). The G-buffer is crafted so that
+    those pixels are lit, face the viewer, and have N.H ~ 0.7 at low roughness: a specular term that is large and well conditioned
+    in |V + L| itself. Both kernels must sit on the oracle like everywhere else; the streaming kernel's waves with such a pixel take
+    |V + L| from the components (csrc/lighting.hip), and the test checks that pixels with 1 + V.L < 1e-3 are really in the frame."""
+    import dataclasses
+    from unclerenderer_amd import hostmath, lib, synth
+    from unclerenderer_amd.hotpath import to_device
+    torch = _torch()
+    w, h = 320, 180
+    base = hostmath.SCENES["sponza"]
+    L = hostmath.build_frame_constants(base, w, h, shadow_size=256).light_direction.astype(np.float64)
+    pos = np.array(base.camera_position, np.float64)
+    preset = dataclasses.replace(base, camera_rotation_deg=None, camera_look_at=tuple(pos + 10.0 * L), light_intensity=3.0)
+    fc = hostmath.build_frame_constants(preset, w, h, shadow_size=256, env_mip_count=6)
+    P = np.asarray(fc.proj, np.float32).reshape(4, 4)
+    V4 = np.asarray(fc.view, np.float32).reshape(4, 4)
+    Lv = (L.astype(np.float32) @ V4[:3, :3]).astype(np.float64)  # light direction in view space: ~(0, 0, 1)
+    assert Lv[2] > 0.999999
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float64) + 0.5, np.arange(h, dtype=np.float64) + 0.5)
+    a, b = (xs / w * 2 - 1) / P[0, 0], -(ys / h * 2 - 1) / P[1, 1]
+    n = np.sqrt(a * a + b * b + 1.0)
+    one_plus_vl = 1.0 - (a * Lv[0] + b * Lv[1] + Lv[2]) / n  # V = -(a, b, 1) / n
+    assert (one_plus_vl < 1e-3).sum() > 100 and (one_plus_vl < 1e-4).sum() > 10
+    r = np.maximum(np.sqrt(a * a + b * b), 1e-9)
+    t2 = np.stack([-a / r, -b / r, np.zeros_like(r)], -1)   # towards the frame's centre: N.V > 0 needs a component along it
+    t1 = np.stack([b / r, -a / r, np.zeros_like(r)], -1)    # across
+    eps = 0.3 * 0.7 * r                                      # N.L = eps > 0, N.V ~ 0.7 * 0.7 r / n > 0, N.H ~ 0.7
+    N = 0.7 * t1 + 0.7 * t2 + eps[..., None] * np.array([0.0, 0.0, 1.0])
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    view_z = np.full((h, w), 5.0)
+    A = np.concatenate([N, -view_z[..., None]], -1).astype(np.float16).view(np.uint16)
+    rough = 0.08 + 0.2 * synth.hash_unit(77, *synth._grid(w, 0, h), 0)
+    B = np.stack([np.full((h, w), 0.04), np.zeros((h, w)), rough, np.ones((h, w))], -1).astype(np.float16).view(np.uint16)
+    Cc = np.full((h, w), 0xFF909090, np.uint32)
+    hdr = np.zeros((h, w, 4), np.float16); hdr[..., 3] = 1.0
+    hdr = hdr.view(np.uint16)
+    shadow = np.ones((256, 256), np.float32)  # nothing in shadow: the direct term is what is being looked at
+    env = synth.env_cube_procedural(32, 6)
+    lut = synth.brdf_lut_procedural(128, 32)
+    tables = _device_tables(hotpath, shadow, env, lut)
+    ref, fragile = oracle.deferred_lighting(fc.scene, A, B, Cc, shadow, env, 32, 6, lut, hdr, w, h, want_fragile=True)
+    reff = ref.view(np.float16).astype(np.float32)
+    near = one_plus_vl < 1e-3
+    assert np.isfinite(reff[near]).all() and reff[near][..., :3].max() > 0.05, "the direct specular term must be visible where V.L -> -1"
+    try:
+        for name, stream in (("streaming", 1), ("per-tile", 0)):
+            hotpath.set_option(lib.UR_OPT_LIGHTING_STREAM, stream)
+            d = to_device(hdr)
+            hotpath.deferred_lighting(fc.scene, to_device(A), to_device(B), to_device(Cc), tables, d, w, h)
+            torch.cuda.synchronize()
+            nbad, worst, where = hdr_mismatch(d.cpu().numpy().view(np.uint16), ref, exclude=fragile)
+            assert nbad == 0, (name, nbad, worst, int((where & near).sum()))
+    finally:
+        hotpath.set_option(lib.UR_OPT_LIGHTING_STREAM, 1)
+    assert fragile.mean() < 0.02
+
+
+def test_env_cube_layout_tag_is_checked(hotpath):
+    """ur_lighting_tables.env_cube_texels carries the staged layout's size: a buffer sized for another layout (round 2 staged the
+    bordered faces only) is refused, not read out of bounds."""
+    from unclerenderer_amd import lib
+    from unclerenderer_amd.hotpath import to_device
+    w, h = 64, 16
+    fc, g, shadow, env, lut = _lighting_inputs("sponza", w, h, seed=3, mode="scene")
+    tables = _device_tables(hotpath, shadow, env, lut)
+    good = tables.env_cube_texels
+    assert good == lib.load().ur_env_cube_texels(32, 6)
+    bordered_only = sum(6 * (max(1, 32 >> m) + 2) ** 2 for m in range(6))
+    for bad in (0, bordered_only, good + 1):
+        tables.env_cube_texels = bad
+        with pytest.raises(lib.UrError) as e:
+            hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, to_device(g.hdr), w, h)
+        assert e.value.code == lib.UR_EINVAL and "another layout" in str(e.value)
+    tables.env_cube_texels = good
+    hotpath.deferred_lighting(fc.scene, to_device(g.A), to_device(g.B), to_device(g.C), tables, to_device(g.hdr), w, h)

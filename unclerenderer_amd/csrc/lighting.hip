@@ -834,8 +834,11 @@ struct HzbRide {
     uint32_t walkers;        // how many waves of a workgroup walk pieces: 1 (the last one) when the band is long - the others shade
                              // meanwhile -, 16 when it is short - the chain must not outlast the shading (informative: the kernel
                              // instantiation, RIDE_ALL, carries the choice)
+    uint32_t want;           // arrivals the riding tail waits for: the launch's lighting workgroups (one more under UR_OPT_DEBUG_HZB_RIDE_STALL)
+    uint32_t spin_limit;     // polls (s_sleep 32 each) before it gives up: 2^22 ~ 4 s
     uint32_t pad;
-    uint32_t* done;          // arrivals of this launch's lighting workgroups (reset by the tail workgroup once it has seen them all)
+    uint32_t* done;          // [0] arrivals of this launch's lighting workgroups (reset by the tail workgroup once it has seen them all);
+                             // [1] sticky: a tail gave up, the host has not reset the words yet (check_hzb_timeout)
     uint32_t* timed_out;     // host-visible (mapped, coherent) flag: the tail gave up waiting (ur_ctx::hzb_timed_out)
 };
 
@@ -868,17 +871,25 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 // the arrival counter is left as it is — stragglers may still add to it; the host resets it when it reports.
                 if (threadIdx.x == 0) {
                     uint32_t* done = ride->done;
-                    const uint32_t want = p.hot.groups;
+                    const uint32_t want = ride->want, limit = ride->spin_limit;
+                    // done[1] != 0: an earlier launch on this context gave up and the host has not put the counter back yet (it does at
+                    // its next entry point, stream-ordered): whatever this launch reads in done[0] may be that launch's leftover, so it
+                    // reports too and leaves the words alone - no frame between a time-out and the host's reset goes unreported
+                    const bool stale = __hip_atomic_load(done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                     uint32_t spins = 0;
                     bool gave_up = false;
                     while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                         __builtin_amdgcn_s_sleep(32);
-                        if (++spins > (1u << 22)) { gave_up = true; break; }
+                        if (++spins > limit) { gave_up = true; break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (gave_up) __hip_atomic_store(ride->timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    else __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the next launch starts from zero
+                    if (gave_up || stale) {
+                        __hip_atomic_store(ride->timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (gave_up) __hip_atomic_store(done + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the next launch starts from zero
+                    }
                 }
                 __syncthreads();
             }
@@ -1208,7 +1219,14 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 float NdotH, om;
                 // V and L are unit vectors: |V + L|^2 = 2 + 2 V.L, N.(V + L) = N.V + N.L, V.(V + L) = 1 + V.L
                 const float VL = fmaf(Vz, L.z, fmaf(Vxy.y, L.y, Vxy.x * L.x));
-                const float hr = rsq(fmaf(VL, 2.0f, 2.0f));
+                float hr = rsq(fmaf(VL, 2.0f, 2.0f));
+                // ... which cancels when the view ray runs along the light (V.L -> -1: 2 + 2 V.L keeps 1e-7 / (1 + V.L) of relative
+                // error). A wave that has such a pixel (a camera looking into the light; uniform, rare) takes |V + L| from the components,
+                // as the shader writes it (PBRCommon.hlsl via DeferredLighting.hlsl:73; tests: test_lighting_view_ray_along_the_light)
+                if (__builtin_expect(flag_any(VL < -0.98f), 0)) {
+                    const float hx = Vxy.x + L.x, hy = Vxy.y + L.y, hz = Vz + L.z;
+                    hr = rsq(fmaf(hz, hz, fmaf(hy, hy, hx * hx)));
+                }
                 NdotH = sat((NdotVraw + NdotLraw) * hr);
                 om = fmaf(-VL, hr, 1.0f - hr); // 1 - VdotH, VdotH = (1 + V.L) / |V + L| in [0,1]: saturate is the identity up to rounding
                 const float alpha = roughness * roughness;
@@ -1456,6 +1474,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
             ride.pieces = ctx->pending_wide_grid_x * ctx->pending_wide_grid_y;
             ride.done = ctx->hzb_done;
             ride.timed_out = ctx->hzb_timed_out_dev;
+            ride.spin_limit = ctx->opt.debug_hzb_ride_stall != 0 ? (1u << 9) : (1u << 22);
             // walkers: the chain should be done within about a quarter of the shading (a piece is ~3 us of one wave's time, a
             // tile ~1.75 us): walkers >= 7 x pieces-per-workgroup / tiles-per-wave, rounded up to a power of two
             {
@@ -1475,6 +1494,7 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
     }
     const uint32_t groups = std::min<uint32_t>((uint32_t)std::max(1, cus - (carry_tail ? 1 : 0) - leave_cus), (h.numTiles + WPB - 1) / WPB);
     h.groups = groups;
+    ride.want = groups + (ctx->opt.debug_hzb_ride_stall != 0 ? 1u : 0u);
     // tile / tilesX by multiplication: exact while (magic * tilesX - 2^32) * tile < 2^32 (checked by the caller)
     h.tilesXMagic = (uint32_t)((1ull << 32) / h.tilesX + 1ull);
     // ---- the run-time part of the schedule (struct Balance): whole rounds of the static deal in front, a pool of chunks behind
@@ -1484,12 +1504,17 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
         constexpr uint32_t cs = kChunkShift;
         const uint32_t round = groups << cs;
         const uint32_t want_pool = (uint32_t)((uint64_t)h.numTiles * (uint32_t)ctx->opt.balance_pool_16ths / 16u);
-        for (uint32_t sh = (uint32_t)ctx->opt.balance_chunk_shift; sh >= 2u; --sh) { // smaller chunks for smaller launches
-            const uint32_t la = sh >= 4u ? 2u : (sh == 3u ? 3u : 4u); // chunks claimed ahead: a claim takes ~1 us, a chunk of 4 tiles lasts 0.5
+        // Chunks of 16 tiles (one tile per wave of a workgroup) and nothing smaller by default: a claim blocks its wave for ~1 us, and
+        // with chunks of 4 tiles a workgroup needs one every 0.5 us - measured, that LOSES 1.5 us at 1080p and 2.2 us on a 540-row
+        // band of a 4K frame (profiles/r04_balance.txt). A launch too short for `lookahead + 2` such chunks per workgroup is dealt
+        // statically as a whole. (UR_OPT_BALANCE_CHUNK_SHIFT below 4 exists for the tests, which drive the claim path hard with it.)
+        do {
+            const uint32_t sh = (uint32_t)ctx->opt.balance_chunk_shift;
+            const uint32_t la = sh >= 4u ? 2u : (sh == 3u ? 3u : 4u); // chunks claimed ahead of use
             const uint32_t rounds = (h.numTiles - want_pool) / round;
             if ((rounds << cs) < 2u * (uint32_t)WPB) break; // (the two tiles of a wave's prologue are static claims)
             const uint32_t static_tiles = rounds * round, chunks = (h.numTiles - static_tiles + (1u << sh) - 1u) >> sh;
-            if (chunks < (la + 2u) * groups) continue;
+            if (chunks < (la + 2u) * groups) break;
             if ((uint64_t)chunks * 8u / groups + la + 8u > kDynSlots) break; // a workgroup's slot table would not hold its word's share
             const unsigned long long magic = (((unsigned long long)chunks << 32) + groups - 1u) / groups;
             bool ok = true;
@@ -1498,14 +1523,13 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
                 const uint32_t P0 = (uint32_t)((q8 * magic) >> 32), P1 = (uint32_t)(((q8 + nq) * magic) >> 32);
                 ok = P1 >= P0 + la * nq && P1 <= chunks;
             }
-            if (!ok) continue;
+            if (!ok) break;
             h.staticClaims = rounds << cs;
             p.bal.poolChunks = chunks; p.bal.staticTiles = static_tiles; p.bal.dynShift = sh; p.bal.lookahead = la;
             p.bal.poolMagic = magic;
             p.bal.words = ctx->claim_words;
             p.bal.timedOut = ctx->claim_timed_out_dev;
-            break;
-        }
+        } while (false);
     }
     const bool ride_all = ride.pieces != 0u && ride.walkers > 1u;
     const kernel_t kern = ride_all ? static_cast<kernel_t>(lighting_stream_kernel<MODE, SHADOWS, IRR_LDS, WPB, true>)
@@ -1599,6 +1623,12 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
         if (p.envMips == 0 || p.envMips > 16 || p.envBase == 0 || T->env_cube == nullptr || T->brdf_lut_rg16 == nullptr ||
             T->lut_width == 0 || T->lut_height == 0) {
             set_error("bad lighting tables");
+            return UR_EINVAL;
+        }
+        if (T->env_cube_texels != (uint64_t)ur_env_cube_texels(p.envBase, p.envMips)) {
+            set_error("ur_lighting_tables.env_cube_texels = %llu, but this version's ur_stage_env_cube writes %llu texels for a %u^2 cube of %u mips: "
+                      "the buffer was sized or staged for another layout", (unsigned long long)T->env_cube_texels,
+                      (unsigned long long)ur_env_cube_texels(p.envBase, p.envMips), p.envBase, p.envMips);
             return UR_EINVAL;
         }
         uint32_t off = 0;

@@ -258,6 +258,7 @@ bool option_slot(int option, OptionSlot& o)
     case UR_OPT_LIGHTING_BALANCE: o = {&O::balance, 0, 1, false}; return true;
     case UR_OPT_BALANCE_POOL_16THS: o = {&O::balance_pool_16ths, 1, 8, false}; return true;
     case UR_OPT_BALANCE_CHUNK_SHIFT: o = {&O::balance_chunk_shift, 2, 6, false}; return true;
+    case UR_OPT_DEBUG_HZB_RIDE_STALL: o = {&O::debug_hzb_ride_stall, 0, 1, false}; return true;
     default: return false;
     }
 }

@@ -60,6 +60,7 @@ struct ur_ctx {
     struct Options {
         int lighting_stream = 1, lighting_wpb = 16, tiled_waves = 6, leave_cus = 0, ride_walkers = 0, cull_store = 2;
         int balance = 1, balance_pool_16ths = 3, balance_chunk_shift = 4;
+        int debug_hzb_ride_stall = 0;
     } opt;
     // Inter-workgroup tile claims of the streaming lighting kernel (UR_OPT_LIGHTING_BALANCE): kClaimWords words, each on a 128-byte
     // line of its own, + the count of workgroups that have made their last claim. All zero between launches: the workgroup whose

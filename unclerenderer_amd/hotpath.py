@@ -161,6 +161,7 @@ class HotPath:
         t.shadow_map = shadow.data_ptr() if shadow is not None else None
         t.env_cube = env_cube.data_ptr()
         t.env_base_size, t.env_mip_count = env_base, env_mips
+        t.env_cube_texels = env_cube.numel() * env_cube.element_size() // 8  # the staged buffer's size in half4 texels = the layout's tag
         t.brdf_lut_rg16 = lut.data_ptr()
         t.lut_height, t.lut_width = int(lut.shape[0]), int(lut.shape[1])
         t._keep = (shadow, env_cube, lut)  # keep the tensors alive

@@ -25,7 +25,7 @@ UR_INDIRECT_INSTANCE_COUNT_OFFSET = 44
 
 # ur_set_option keys (include/ur_hotpath.h)
 UR_OPT_LIGHTING_STREAM, UR_OPT_LIGHTING_WAVES_PER_WG, UR_OPT_LIGHTING_TILED_WAVES, UR_OPT_LIGHTING_LEAVE_CUS, UR_OPT_RIDE_WALKERS = 1, 2, 3, 4, 5
-UR_OPT_CULL_STORE, UR_OPT_LIGHTING_BALANCE, UR_OPT_BALANCE_POOL_16THS, UR_OPT_BALANCE_CHUNK_SHIFT = 7, 8, 9, 10
+UR_OPT_CULL_STORE, UR_OPT_LIGHTING_BALANCE, UR_OPT_BALANCE_POOL_16THS, UR_OPT_BALANCE_CHUNK_SHIFT, UR_OPT_DEBUG_HZB_RIDE_STALL = 7, 8, 9, 10, 11
 
 
 class MipDesc(C.Structure):
@@ -67,7 +67,7 @@ class SkyConstants(C.Structure):
 class LightingTables(C.Structure):
     _fields_ = [
         ("shadow_map", C.c_void_p), ("env_cube", C.c_void_p), ("env_base_size", C.c_uint32), ("env_mip_count", C.c_uint32),
-        ("brdf_lut_rg16", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
+        ("brdf_lut_rg16", C.c_void_p), ("lut_width", C.c_uint32), ("lut_height", C.c_uint32), ("env_cube_texels", C.c_uint64),
     ]
 
 
