@@ -231,7 +231,7 @@ def test_c1_duck_512_whole_frame(hotpath, oracle, d24):
     ref_hzb = np.nan_to_num(oracle.build_hzb(depth, lay.as_list(), lay.total))
     lit, frag = oracle.deferred_lighting(fc.scene, g.A, g.B, g.C, shadow, env, 256, 9, lut, g.hdr, w, h, want_fragile=True)
     ref_hdr = oracle.sky_atmosphere(fc.sky, depth, lit, w, h)
-    assert (ref_hdr.view(np.float16).astype(np.float32)[..., :3] > 2.0).mean() > 0.01, "the fixture must reach the one-ulp branch of the tolerance"
+    assert (ref_hdr.view(np.float16).astype(np.float32)[..., :3] > 2.0).mean() > 0.002, "the fixture must reach the one-ulp branch of the tolerance"
     frame = Frame(hotpath)
     try:
         for k, flags in enumerate((lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY,
