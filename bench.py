@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--hzb-launch", choices=["ride", "tail-rides", "separate"], default="ride",
                     help="ride: the whole Build HZB chain rides along with the Lighting launch (two launches per frame); tail-rides: only its "
                          "single-workgroup tail does (three launches); separate: Build HZB is launches of its own (four)")
+    ap.add_argument("--hzb", choices=["replicate", "shard"], default="replicate",
+                    help="N > 1: replicate = every rank builds the whole HZB chain from the whole depth buffer (no exchange); shard = a rank builds "
+                         "mips 0-4 for the 128x32 pieces its rows own (riding its Lighting launch), the slices cross peer to peer and the "
+                         "single-workgroup tail runs on every rank behind the exchange (ur_build_hzb_band, dist.allgather_hzb_slices)")
     ap.add_argument("--separate-hzb-tail", action="store_true",
                     help="launch the single-workgroup tail of Build HZB on its own (three visibility launches per frame) instead of "
                          "letting it ride along with the Lighting launch as an extra workgroup")
@@ -220,6 +224,10 @@ def main():
         flags |= urlib.UR_FRAME_HZB_TAIL_WITH_LIGHTING
     if args.gather_ldr:
         flags |= urlib.UR_FRAME_TONEMAP
+    shard_hzb = args.hzb == "shard" and N > 1 and not args.async_compute
+    if shard_hzb:
+        flags |= urlib.UR_FRAME_HZB_SHARD
+    hzb_sent = [0]
     if args.async_compute:
         # visibility passes on the async-compute stream; joined once before the timed region closes (nothing on the
         # main stream consumes their outputs or overwrites their inputs inside the loop)
@@ -269,6 +277,11 @@ def main():
             s["graph"].replay()
         else:
             frame.render(s["res"], cull_consts, fc.scene, fc.sky, timed_flags if (timed and k % light_every == 0) else flags)
+        if shard_hzb:
+            # the frame built this rank's pieces of mips 0-4: exchange the slices (peer to peer, into place) and run the tail. The
+            # next frame's cull reads this HZB, so the exchange is waited for here (it is ~1.4 MB per peer at 4K / 8)
+            hzb_sent[0] = urdist.allgather_hzb_slices(hzb, lay)[0]
+            hp.build_hzb_tail(hzb, lay)
         if N > 1:
             # RCCL all-gather of the bands on the communication stream, behind this frame's passes; the next frames (other
             # buffer sets of the ring) are shaded while it runs — frames in flight, as the reference keeps three
@@ -457,6 +470,7 @@ def main():
             "gbuffer": args.gbuffer, "background_fraction": round(float(n_sky) / g.depth.size, 4),
             "ibl_tables": ibl_desc,
             "frame_buffer_ring": ring, "parallelism": f"rowbands{N}",
+            "hzb_build": ("band-sharded: mips 0-4 per rank + peer-to-peer exchange of %d B per peer + replicated tail" % hzb_sent[0]) if shard_hzb else ("replicated on every rank" if N > 1 else "one rank"),
             "async_compute": args.async_compute, "hip_graph": bool(args.graph), "hzb_launch": "separate launches" if (args.hzb_launch == "separate" or args.async_compute) else ("whole chain rides with the Lighting launch" if args.hzb_launch == "ride" else "tail rides with the Lighting launch"), "driver": "FRenderGraph (csrc/frame/HotPathRenderer.cpp)", "frames_in_flight": args.frames_in_flight,
         },
         "roofline": {

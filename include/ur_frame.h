@@ -54,6 +54,7 @@ typedef struct ur_frame_resources {
 #define UR_FRAME_TIME_LIGHTING_RECORD_COST 0x8000u /* TIME_LIGHTING plus one more event recorded right behind the pair: its distance to the pair's closing event is what an event record costs on this queue (ur_frame_lighting_times_ex) */
 #define UR_FRAME_HZB_WITH_LIGHTING 0x4000u /* the WHOLE Build HZB chain rides along with the Lighting launch (ur_defer_hzb_tail(ctx, 2)): its 128x32 pieces are walked by one wave of every lighting workgroup, its tail by an extra workgroup that waits for them; two launches per frame (cull, lighting). Ignored with ASYNC_COMPUTE */
 #define UR_FRAME_TIME_LIGHTING_KERNEL 0x10000u /* time the Lighting pass by a HIP event pair carried on its kernel dispatch (ur_time_next_lighting): from the end of what precedes the kernel to the kernel's end, what rocprofv3's kernel trace reports for the dispatch; no event record behind the kernel; read with ur_frame_lighting_times() */
+#define UR_FRAME_HZB_SHARD 0x20000u /* several ranks (ur_frame_create's world_size > 1): Build HZB builds only this rank's 128x32 pieces of mips 0..4 (ur_build_hzb_band; riding the Lighting launch with HZB_WITH_LIGHTING) and leaves the exchange of the slices and the tail (ur_build_hzb_tail) to the caller, who holds the communicator. One rank: the whole chain as usual */
 #define UR_FRAME_DEFAULT (UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY)
 
 ur_frame* ur_frame_create(ur_ctx* ctx, void* stream, uint32_t frames_in_flight, int rank, int world_size);

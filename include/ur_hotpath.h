@@ -229,6 +229,24 @@ uint32_t ur_hzb_layout(uint32_t src_w, uint32_t src_h, ur_mip_desc* mips /*host,
 int ur_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base,
                  const ur_mip_desc* mips, uint32_t mip_count);
 
+/* Band-sharded Build HZB for row-band sharding over several GPUs (no counterpart in the reference, which has one adapter; SURVEY.md
+ * section 8e). The first launch of the chain (depth -> mips 0..4) works on 128 x 32-pixel source pieces, and every value of those
+ * five levels depends on its own piece only: a rank builds the piece rows whose first source row lies in its band
+ * (ur_hzb_band_pieces; it needs the depth rows of those pieces, i.e. up to 31 rows below its band), the ranks exchange the
+ * slices (ur_hzb_band_slices names them: one contiguous run of floats per level), and every rank runs the single-workgroup rest of
+ * the chain (ur_build_hzb_tail: mips 5.. from mip 4) behind the exchange. Bit for bit ur_build_hzb's chain. Only for chains that are
+ * one five-level launch plus the tail (frames of a few hundred pixels up to 8K); UR_EUNSUPPORTED otherwise (build it whole).
+ * With ur_defer_hzb_tail(ctx, 2) the band's pieces ride the next streaming Lighting launch like the whole chain's do. */
+typedef struct ur_hzb_slice {
+    uint32_t offset; /* in floats from hzb_base */
+    uint32_t count;  /* floats */
+} ur_hzb_slice;
+int ur_hzb_band_pieces(uint32_t src_h, uint32_t n_ranks, uint32_t rank, uint32_t* piece_row0, uint32_t* piece_rows);
+int ur_hzb_band_slices(const ur_mip_desc* mips, uint32_t mip_count, uint32_t piece_row0, uint32_t piece_rows, ur_hzb_slice* out5);
+int ur_build_hzb_band(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base, const ur_mip_desc* mips,
+                      uint32_t mip_count, uint32_t piece_row0, uint32_t piece_rows);
+int ur_build_hzb_tail(ur_ctx* ctx, float* hzb_base, const ur_mip_desc* mips, uint32_t mip_count);
+
 /* ---- CullIndirectArgs (+ visible-list compaction) ---------------------------------------------- */
 
 /* constants: host, the 46 root constants packed by FRenderer::DispatchGpuCulling (Renderer.cpp:411-429):

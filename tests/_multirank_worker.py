@@ -37,7 +37,7 @@ def c4_inputs(w, h, row0, rows):
     return fc, g, depth_full, shadow, sb.bounds
 
 
-def c4_render(hp, w, h, rank, world, frames=2):
+def c4_render(hp, w, h, rank, world, frames=2, shard_hzb=False):
     """The frame as bench.py drives it (render graph: cull with last frame's HZB -> Build HZB riding the fused Lighting+Sky
     launch -> Tonemap), `frames` times so that the last cull reads an HZB. Returns the device tensors of the band."""
     import torch
@@ -62,10 +62,17 @@ def c4_render(hp, w, h, rank, world, frames=2):
                           d["bounds"], d["args"], i1 - i0, i0, d["vis"], d["cnt"], None, d["ldr_band"])
     consts = hostmath.pack_culling_constants(fc.view, fc.proj, i1 - i0, True, lay.count, lay.width, lay.height, False)
     flags = lib.UR_FRAME_DEFAULT | lib.UR_FRAME_FUSE_LIGHTING_SKY | lib.UR_FRAME_HZB_WITH_LIGHTING | lib.UR_FRAME_TONEMAP
+    if shard_hzb:
+        flags |= lib.UR_FRAME_HZB_SHARD  # (one rank: the whole chain as usual)
     hdr0 = d["hdr_band"].clone()
     for k in range(frames):
         d["hdr_band"].copy_(hdr0)  # (the Lighting pass blends into its target: every frame starts from the emissive pre-fill)
         frame.render(res, consts, fc.scene, fc.sky, flags)
+        if shard_hzb and world > 1:
+            # band-sharded Build HZB: the frame built this rank's pieces of mips 0..4 (riding its Lighting launch); the ranks
+            # exchange the slices peer to peer and every rank runs the tail - what bench.py --hzb shard does per frame
+            d["hzb_sent"] = urdist.allgather_hzb_slices(d["hzb"], lay)[0]
+            hp.build_hzb_tail(d["hzb"], lay)
     torch.cuda.synchronize()
     frame.close()
     return plan, d, n
@@ -130,6 +137,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--instances", type=int, default=1_000_000)
+    ap.add_argument("--shard-hzb", action="store_true")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
@@ -142,8 +150,10 @@ def main():
     try:
         if a.case == "c4":
             w, h = a.width, a.height
-            plan, d, n = c4_render(hp, w, h, rank, world)
+            plan, d, n = c4_render(hp, w, h, rank, world, shard_hzb=a.shard_hzb)
             out = gather_all(torch, urdist, plan, d, w, h, n, world)
+            if a.shard_hzb:
+                out["hzb"] = d["hzb"].clone()  # complete on every rank: gathered slices + the replicated tail
         else:
             n = a.instances
             d, _ = c5_cull(hp, n, rank, world)

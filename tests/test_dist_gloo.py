@@ -107,3 +107,56 @@ def test_plans():
     h = torch.zeros((4, 2, 4), dtype=torch.int16)
     urdist.allgather_hdr(h, torch.ones((4, 2, 4), dtype=torch.int16))  # world 1: plain copy
     assert (h == 1).all()
+
+
+def _hzb_worker(rank, world, port, w, h, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as o
+        from unclerenderer_amd import synth
+        from unclerenderer_amd.hotpath import HzbLayout
+        depth = (synth.hash_unit(23, *synth._grid(w, 0, h), 0)).astype(np.float32)
+        lay = HzbLayout(w, h)
+        ref = np.nan_to_num(o.build_hzb(depth, lay.as_list(), lay.total))
+        mine = np.full(lay.total, -1.0, np.float32)  # what this rank has after its band launch: its own slices of mips 0..4, nothing else
+        for off, cnt in lay.band_slices(*lay.band_pieces(world, rank)):
+            mine[off:off + cnt] = ref[off:off + cnt]
+        t = torch.from_numpy(mine)
+        sent, _ = urdist.allgather_hzb_slices(t, lay)
+        sent2, work = urdist.allgather_hzb_slices(t, lay, async_op=True)  # idempotent; the handle form
+        work.wait()
+        assert sent == sent2 == 4 * sum(c for _, c in lay.band_slices(*lay.band_pieces(world, rank)))
+        np.save(os.path.join(out_dir, f"hzb{rank}.npy"), t.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_sharded_hzb_slices_gather_into_the_whole_levels(tmp_path, oracle, urlib, world):
+    """Band-sharded Build HZB (ur_build_hzb_band + dist.allgather_hzb_slices): the piece rows of the ranks partition the wide
+    launch's pieces, their slices partition mips 0..4, and after the peer-to-peer exchange every rank holds those five levels
+    whole (the tail levels are each rank's own launch afterwards)."""
+    from unclerenderer_amd import synth
+    from unclerenderer_amd.hotpath import HzbLayout
+    w, h = 640, 360
+    lay = HzbLayout(w, h)
+    pieces = [lay.band_pieces(world, r) for r in range(world)]
+    assert pieces[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(pieces, pieces[1:])) and sum(p[1] for p in pieces) == (h + 31) // 32
+    covered = np.zeros(lay.total, np.int32)
+    for p in pieces:
+        for off, cnt in lay.band_slices(*p):
+            covered[off:off + cnt] += 1
+    for k in range(lay.count):
+        m = lay.mips[k]
+        lvl = covered[m.offset:m.offset + m.width * m.height]
+        assert (lvl == (1 if k < 5 else 0)).all(), k
+    mp.spawn(_hzb_worker, args=(world, _free_port(), w, h, str(tmp_path)), nprocs=world, join=True)
+    depth = (synth.hash_unit(23, *synth._grid(w, 0, h), 0)).astype(np.float32)
+    ref = np.nan_to_num(oracle.build_hzb(depth, lay.as_list(), lay.total))
+    for r in range(world):
+        got = np.load(tmp_path / f"hzb{r}.npy")
+        for k in range(5):
+            m = lay.mips[k]
+            sl = slice(m.offset, m.offset + m.width * m.height)
+            assert np.array_equal(got[sl].view(np.uint32), ref[sl].view(np.uint32)), (r, k)

@@ -71,3 +71,28 @@ def test_c5_two_ranks_cull_1m_like_one(hotpath, spawn_ranks, tmp_path):
     assert np.array_equal(got["vis"], d["vis"].cpu().numpy()[:cnt]), "visible list"
     assert np.array_equal(got["args"], d["args"].cpu().numpy().view(np.int32).reshape(-1, 16)), "InstanceCount words"
     assert np.array_equal(got["stats"], d["stats"].cpu().numpy()), "frustum-culled / occluded counters sum to the single-rank ones"
+
+
+@pytest.mark.parametrize("w,h", [(3840, 2160), (1904, 1052)])
+def test_c4_two_ranks_with_band_sharded_hzb(hotpath, spawn_ranks, tmp_path, w, h):
+    """The same frame with Build HZB band-sharded (UR_FRAME_HZB_SHARD): each rank builds mips 0..4 for the 128x32 pieces its rows own,
+    riding its Lighting launch, the slices cross peer to peer (dist.allgather_hzb_slices) and the tail is replicated behind the
+    exchange. After two frames the HZB on every rank, the cull that read it (visible list, InstanceCount words) and the HDR / LDR
+    frames are byte for byte the single-rank chain's - at 4K and at an odd size (1052 rows: bands of 526 rows, 16.4 pieces)."""
+    import torch
+    from tests._multirank_worker import c4_render
+    got = _run_ranks(spawn_ranks, "c4", tmp_path, extra=("--shard-hzb", "--width", str(w), "--height", str(h)))
+    plan, d, n = c4_render(hotpath, w, h, 0, 1)
+    torch.cuda.synchronize()
+    from unclerenderer_amd.hotpath import HzbLayout
+    lay = HzbLayout(w, h)
+    valid = np.zeros(lay.total, bool)
+    for off, mw, mh in lay.as_list():
+        valid[off:off + mw * mh] = True
+    ref_hzb = d["hzb"].cpu().numpy()
+    assert np.array_equal(got["hzb"].view(np.uint32)[valid], ref_hzb.view(np.uint32)[valid]), "gathered slices + replicated tail == the single-rank chain"
+    assert np.array_equal(got["hdr_ring"], d["hdr_band"].cpu().numpy())
+    assert np.array_equal(got["ldr_direct"], d["ldr_band"].cpu().numpy())
+    cnt = int(d["cnt"].cpu()[0])
+    assert np.array_equal(got["vis"], d["vis"].cpu().numpy()[:cnt]) and cnt > 0
+    assert np.array_equal(got["args"], d["args"].cpu().numpy().view(np.int32).reshape(-1, 16))

@@ -79,7 +79,7 @@ def test_streaming_kernels_have_no_scratch_and_no_spills(lighting_co):
     hot = next(v for k, v in meta.items() if HOT in k)
     # (an SGPR spill is a v_writelane / v_readlane pair, not scratch memory; the two the bench kernel has are written ahead of
     # the loop and read behind it: test_no_spill_traffic_inside_the_loop)
-    assert hot["private_segment_fixed_size"] == 0 and hot["vgpr_spill_count"] == 0 and hot["sgpr_spill_count"] <= 4, hot
+    assert hot["private_segment_fixed_size"] == 0 and hot["vgpr_spill_count"] == 0 and hot["sgpr_spill_count"] <= 8, hot
     assert hot["vgpr_count"] <= 128, hot  # 4 waves per SIMD need <= 128
     for name, m in meta.items():
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)

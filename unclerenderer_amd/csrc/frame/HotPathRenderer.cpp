@@ -73,6 +73,7 @@ int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Re
     struct FHZBPassData
     {
         uint32 Width = 0, Height = 0, MipCount = 0, SourceWidth = 0, SourceHeight = 0;
+        bool bShard = false;
     };
     if (bHZBEnabled && Options.bDoDepthPrepass) {
         Graph.AddPass<FHZBPassData>("Build HZB", [&](FHZBPassData& Data, FRGPassBuilder& Builder)
@@ -82,13 +83,21 @@ int FHotPathRenderer::RenderFrame(FHIPCommandContext& Cmd, FHotPathResources& Re
             Data.MipCount = Res.HZBMipCount;
             Data.SourceWidth = Res.Width;
             Data.SourceHeight = Res.Height;
+            Data.bShard = Options.bShardHZB;
             Builder.ReadTexture(DepthHandle, RG_STATE_NON_PIXEL_SHADER_RESOURCE);
             Builder.WriteTexture(HZBHandle, RG_STATE_UNORDERED_ACCESS);
             if (Options.bAsyncCompute) Builder.AsyncCompute();
         }, [this, &Res](const FHZBPassData& Data, FHIPCommandContext& Cmd)
         {
             if (Data.MipCount == 0) return;
-            const int rc = ur_build_hzb(Cmd.GetContext(), Res.DepthFull, Data.SourceWidth, Data.SourceHeight, Res.HZB, Res.HZBMips, Data.MipCount);
+            int rc;
+            if (Data.bShard) { // this rank's piece rows of the wide launch; the ranks' exchange and the tail are the caller's (it holds the communicator)
+                uint32_t Row0 = 0, Rows = 0;
+                rc = ur_hzb_band_pieces(Data.SourceHeight, static_cast<uint32_t>(Cmd.GetWorldSize()), static_cast<uint32_t>(Cmd.GetRank()), &Row0, &Rows);
+                if (rc == UR_OK) rc = ur_build_hzb_band(Cmd.GetContext(), Res.DepthFull, Data.SourceWidth, Data.SourceHeight, Res.HZB, Res.HZBMips, Data.MipCount, Row0, Rows);
+            } else {
+                rc = ur_build_hzb(Cmd.GetContext(), Res.DepthFull, Data.SourceWidth, Data.SourceHeight, Res.HZB, Res.HZBMips, Data.MipCount);
+            }
             if (rc != UR_OK && PassError == UR_OK) PassError = rc;
             Res.HZBState = RG_STATE_NON_PIXEL_SHADER_RESOURCE; // :1209
             if (rc == UR_OK) bHZBReady = true;                  // :1210
@@ -317,6 +326,7 @@ int ur_frame_render(ur_frame* f, const ur_frame_resources* r, const uint32_t* cu
     O.bSkyEnabled = (flags & UR_FRAME_SKY) != 0;
     O.bFuseLightingAndSky = (flags & UR_FRAME_FUSE_LIGHTING_SKY) != 0;
     O.bTonemap = (flags & UR_FRAME_TONEMAP) != 0;
+    O.bShardHZB = (flags & UR_FRAME_HZB_SHARD) != 0 && f->Cmd.GetWorldSize() > 1;
     O.bAsyncCompute = (flags & UR_FRAME_ASYNC_COMPUTE) != 0;
     if (O.bAsyncCompute && !f->AsyncCtx) { // second stream + a context bound to it, created on first use
         int dev = 0;

@@ -63,6 +63,7 @@ struct FHotPathOptions
 {
     bool bEnableIndirectDraw = true;  // RendererConfig IndirectDraw
     bool bHZBEnabled = true;
+    bool bShardHZB = false;           // several ranks: build only this rank's pieces of mips 0..4 (the caller gathers and runs the tail)
     bool bDoDepthPrepass = true;      // HZB is only built when the depth prepass ran (:996)
     bool bRenderShadows = true;
     bool bSkyEnabled = true;

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
     __shared__ float sh3[2][8];
 
     const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
-    const uint32_t x1 = blockIdx.x * 32u + tx, y1 = blockIdx.y * 8u + ty; // coords in mip k+1 (== 4x4 source block index)
+    const uint32_t by = blockIdx.y + p.by0; // (a band-sharded launch starts at its rank's first piece row)
+    const uint32_t x1 = blockIdx.x * 32u + tx, y1 = by * 8u + ty; // coords in mip k+1 (== 4x4 source block index)
     const uint32_t sx = x1 * 4u, sy = y1 * 4u;
 
     // ---- mip k: four texels (2x1+i, 2y1+j) from the 4x4 source block, clamped reads (SampleDepth, :34-39)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
     //      launch starts from a mip a quarter the size: clamped 2x2 footprints of mip k+3 (SampleDepth, :34-39). The
     //      workgroup's 8x2 texels of mip k+3 hold every tap: a clamped coordinate of an in-range texel stays in its pair.
     if (threadIdx.x < 4u) {
-        const uint32_t x4 = blockIdx.x * 4u + threadIdx.x, y4 = blockIdx.y;
+        const uint32_t x4 = blockIdx.x * 4u + threadIdx.x, y4 = by;
         if (x4 < p.W[4] && y4 < p.H[4]) {
             const uint32_t c0 = min(2u * x4, p.W[3] - 1u) & 7u, c1 = min(2u * x4 + 1u, p.W[3] - 1u) & 7u;
             const uint32_t r0 = min(2u * y4, p.H[3] - 1u) & 1u, r1 = min(2u * y4 + 1u, p.H[3] - 1u) & 1u;
@@ -129,6 +130,8 @@ __global__ __launch_bounds__(1024) void hzb_tail_kernel(ur::HzbTail p)
 
 namespace ur {
 
+static HzbTail make_tail(float* hzb, const ur_mip_desc* mips, uint32_t mip_count, uint32_t mip);
+
 int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb, const ur_mip_desc* mips,
                      uint32_t mip_count)
 {
@@ -142,18 +145,7 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
     uint32_t mip = 0;
     while (mip < mip_count) {
         if (mip > 0 && (uint64_t)mips[mip].width * mips[mip].height <= kTailTexels && mip_count - mip <= kTailMaxLevels) {
-            HzbTail t{};
-            t.src = hzb + mips[mip - 1].offset;
-            t.SW = mips[mip - 1].width;
-            t.SH = mips[mip - 1].height;
-            t.first_mip = mip;
-            t.levels = mip_count - mip;
-            for (uint32_t k = 0; k < t.levels; ++k) {
-                t.dst[k] = hzb + mips[mip + k].offset;
-                t.W[k] = mips[mip + k].width;
-                t.H[k] = mips[mip + k].height;
-                t.magic[k] = t.W[k] > 1u ? (uint32_t)((1ull << 32) / t.W[k] + 1ull) : 0u; // W == 1: y = i (handled in the kernel)
-            }
+            const HzbTail t = make_tail(hzb, mips, mip_count, mip);
             if (ctx->defer_hzb_tail) { // the next streaming Lighting launch takes it along (lighting.hip); ur_flush otherwise
                 ctx->pending_tail = t;
                 ctx->hzb_tail_pending = true;
@@ -213,6 +205,78 @@ int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t s
         UR_HIP_TRY(hipGetLastError());
         mip += n;
     }
+    return UR_OK;
+}
+
+// ---- band-sharded chain (multi-GPU, SURVEY.md section 8e row 3's alternative): a rank builds mips 0..4 for the 128x32 source pieces
+// whose first row lies in its band - every value of those levels depends on its own piece only, so the slices are the whole-frame
+// launch's bits -, the slices are all-gathered by the host, and the single-workgroup tail (mips 5..) runs on every rank behind it.
+static bool chain_is_wide_plus_tail(const ur_mip_desc* mips, uint32_t mip_count)
+{
+    return mip_count > 5u && (uint64_t)mips[5].width * mips[5].height <= kTailTexels && mip_count - 5u <= kTailMaxLevels;
+}
+
+static HzbTail make_tail(float* hzb, const ur_mip_desc* mips, uint32_t mip_count, uint32_t mip)
+{
+    HzbTail t{};
+    t.src = hzb + mips[mip - 1].offset;
+    t.SW = mips[mip - 1].width;
+    t.SH = mips[mip - 1].height;
+    t.first_mip = mip;
+    t.levels = mip_count - mip;
+    for (uint32_t k = 0; k < t.levels; ++k) {
+        t.dst[k] = hzb + mips[mip + k].offset;
+        t.W[k] = mips[mip + k].width;
+        t.H[k] = mips[mip + k].height;
+        t.magic[k] = t.W[k] > 1u ? (uint32_t)((1ull << 32) / t.W[k] + 1ull) : 0u; // W == 1: y = i (handled in the kernel)
+    }
+    return t;
+}
+
+int launch_build_hzb_band(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb, const ur_mip_desc* mips, uint32_t mip_count,
+                          uint32_t piece_row0, uint32_t piece_rows)
+{
+    {
+        const int rc = flush_hzb_tail(ctx);
+        if (rc != UR_OK) return rc;
+    }
+    if (!chain_is_wide_plus_tail(mips, mip_count)) {
+        set_error("ur_build_hzb_band: a %u x %u frame's chain is not one five-level launch plus the tail (build it whole: ur_build_hzb)", src_w, src_h);
+        return UR_EUNSUPPORTED;
+    }
+    HzbDispatch d{};
+    d.src = depth; d.SW = src_w; d.SH = src_h;
+    for (uint32_t k = 0; k < 5; ++k) { d.dst[k] = hzb + mips[k].offset; d.W[k] = mips[k].width; d.H[k] = mips[k].height; }
+    d.mips = 5u;
+    d.vec4_ok = ((d.SW & 3u) == 0u && (reinterpret_cast<uintptr_t>(d.src) & 15u) == 0u) ? 1u : 0u;
+    d.pair_ok = ((d.W[0] & 1u) == 0u && (reinterpret_cast<uintptr_t>(d.dst[0]) & 7u) == 0u) ? 1u : 0u;
+    d.by0 = piece_row0;
+    const dim3 grid((d.W[0] + 63u) / 64u, piece_rows);
+    if (piece_rows == 0u) return UR_OK;
+    if (ctx->defer_hzb_tail && ctx->defer_hzb_wide) { // rides the next streaming Lighting launch (no tail: it waits for the gather)
+        ctx->pending_wide = d;
+        ctx->pending_wide_grid_x = grid.x;
+        ctx->pending_wide_grid_y = grid.y;
+        ctx->hzb_wide_pending = true;
+        return UR_OK;
+    }
+    hipLaunchKernelGGL(hzb_reduce4_kernel, grid, dim3(256), 0, ctx->stream, d);
+    UR_HIP_TRY(hipGetLastError());
+    return UR_OK;
+}
+
+int launch_build_hzb_tail(ur_ctx* ctx, float* hzb, const ur_mip_desc* mips, uint32_t mip_count)
+{
+    {
+        const int rc = flush_hzb_tail(ctx);
+        if (rc != UR_OK) return rc;
+    }
+    if (!chain_is_wide_plus_tail(mips, mip_count)) {
+        set_error("ur_build_hzb_tail: the chain is not one five-level launch plus the tail");
+        return UR_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(hzb_tail_kernel, dim3(1), dim3(1024), 0, ctx->stream, make_tail(hzb, mips, mip_count, 5u));
+    UR_HIP_TRY(hipGetLastError());
     return UR_OK;
 }
 

@@ -23,6 +23,8 @@ struct HzbDispatch {
     uint32_t mips; // 1..4 as the reference dispatches; 5 = also the first level of the NEXT reference dispatch
     uint32_t vec4_ok; // SW % 4 == 0 and src 16-byte aligned
     uint32_t pair_ok; // W[0] even and dst[0] 8-byte aligned
+    uint32_t by0;     // first 128x32 piece row of this dispatch (0 for the whole frame; a rank's first piece row when the launch is
+                      // band-sharded: ur_build_hzb_band)
 };
 
 __device__ __forceinline__ float hzbw_min4(float a, float b, float c, float d) { return fminf(fminf(a, b), fminf(c, d)); }

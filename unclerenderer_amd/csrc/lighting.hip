@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 const uint32_t first = RIDE_ALL ? blockIdx.x + (kWalkers - 1u - wave) * groups : blockIdx.x, step = RIDE_ALL ? groups * kWalkers : groups;
                 for (uint32_t piece = first; piece < pieces; piece += step) { // uniform
                     const uint32_t by = piece / gx, bx = piece - by * gx;
-                    ur::hzb_wide_piece_by_one_wave<true>(ride->d, bx, by, lane, sh2, sh2 + 64);
+                    ur::hzb_wide_piece_by_one_wave<true>(ride->d, bx, by + ride->d.by0, lane, sh2, sh2 + 64);
                 }
                 // producer side of the hand-off: mip 4 was stored write-through (sc1); the wave's stores drained, then ONE
                 // arrival per workgroup. (A release fence instead would write back everything the lighting waves have dirtied
@@ -1057,10 +1057,10 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 // A single-lane device-scope add (agent scope is the default for global atomics on gfx950), written as an
                 // instruction with EXEC narrowed to lane 0: the same statement as C++ under `if (lane == 0)` makes hipcc keep the
                 // loop's LDS-DMA destination (an SGPR operand of inline asm) in a VGPR.
-                if (signals) { // uniform
+                uint32_t* done = ride->done; // null: nobody inside this launch waits for the pieces (a band-sharded chain: ur_build_hzb_band)
+                if (signals && done != nullptr) { // uniform
                     uint64_t keep_exec;
                     const uint32_t zero = 0u, one = 1u;
-                    uint32_t* done = ride->done;
                     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %1, %2, %3\n\ts_mov_b64 exec, %0"
                                  : "=&s"(keep_exec)
                                  : "v"(zero), "v"(one), "s"(done)
@@ -1488,6 +1488,19 @@ int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk i
             }
             ctx->hzb_wide_pending = false;
         }
+    } else if (ctx->hzb_wide_pending && !ctx->hzb_tail_pending && WPB == 16 && cus >= 16) {
+        // a band-sharded chain's pieces (ur_build_hzb_band) ride without a tail: the tail waits for the ranks' gather. Nothing inside
+        // the launch consumes the pieces, so no arrival is signalled (done stays null) and no CU is set aside.
+        ride.d = ctx->pending_wide;
+        ride.grid_x = ctx->pending_wide_grid_x;
+        ride.pieces = ctx->pending_wide_grid_x * ctx->pending_wide_grid_y;
+        const uint32_t lighting_groups = std::max(1, cus - leave_cus);
+        const double per_group = (double)ride.pieces / lighting_groups, tiles_per_wave = (double)h.numTiles / (lighting_groups * WPB);
+        uint32_t wk = 1;
+        while (wk < (uint32_t)WPB && (double)wk * tiles_per_wave < 7.0 * per_group) wk *= 2;
+        if (ctx->opt.ride_walkers >= 1) wk = (uint32_t)ctx->opt.ride_walkers;
+        ride.walkers = wk >= 4u ? (uint32_t)WPB : 1u;
+        ctx->hzb_wide_pending = false;
     } else if (ctx->hzb_wide_pending) { // cannot ride (12-wave build, tiny device): the ordinary launches, in front
         const int frc = ur::flush_hzb_tail(ctx);
         if (frc != UR_OK) return frc;

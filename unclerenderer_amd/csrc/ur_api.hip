@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -379,6 +380,47 @@ int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_fl
     const int rc = cull_checked(ctx, constants, bounds, hzb_base, mips, indirect_args, stats2, visible_idx, visible_count, index_base);
     if (ctx) ctx->time_cull_stop = nullptr; // one-shot whatever the call did (ur_time_next_cull)
     return rc;
+}
+
+int ur_hzb_band_pieces(uint32_t src_h, uint32_t n_ranks, uint32_t rank, uint32_t* piece_row0, uint32_t* piece_rows)
+{
+    if (src_h == 0 || n_ranks == 0 || rank >= n_ranks || src_h % n_ranks != 0 || !piece_row0 || !piece_rows) { set_error("ur_hzb_band_pieces: bad argument"); return UR_EINVAL; }
+    const uint32_t rows = src_h / n_ranks;
+    const uint32_t first = (rank * rows + 31u) / 32u, last = ((rank + 1u) * rows + 31u) / 32u; // pieces whose first source row lies in the band
+    *piece_row0 = first;
+    *piece_rows = last - first;
+    return UR_OK;
+}
+
+int ur_hzb_band_slices(const ur_mip_desc* mips, uint32_t mip_count, uint32_t piece_row0, uint32_t piece_rows, ur_hzb_slice* out5)
+{
+    if (!mips || mip_count < 5 || !out5) { set_error("ur_hzb_band_slices: bad argument"); return UR_EINVAL; }
+    for (uint32_t k = 0; k < 5; ++k) {
+        const uint32_t per = 16u >> k, H = mips[k].height, W = mips[k].width;
+        const uint32_t r0 = std::min(piece_row0 * per, H), r1 = std::min((piece_row0 + piece_rows) * per, H);
+        out5[k].offset = mips[k].offset + r0 * W;
+        out5[k].count = (r1 - r0) * W;
+    }
+    return UR_OK;
+}
+
+int ur_build_hzb_band(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base, const ur_mip_desc* mips, uint32_t mip_count,
+                      uint32_t piece_row0, uint32_t piece_rows)
+{
+    if (!ctx || !depth || !hzb_base || src_w == 0 || src_h == 0) { set_error("ur_build_hzb_band: null/zero argument"); return UR_EINVAL; }
+    if (!valid_hzb_chain(src_w, src_h, mips, mip_count)) { set_error("ur_build_hzb_band: mip chain does not match CreateHZBResources sizing"); return UR_EINVAL; }
+    if ((uint64_t)piece_row0 + piece_rows > (src_h + 31u) / 32u) { set_error("ur_build_hzb_band: piece rows [%u, %u) of %u", piece_row0, piece_row0 + piece_rows, (src_h + 31u) / 32u); return UR_EINVAL; }
+    const int trc = ur::check_hzb_timeout(ctx, "ur_build_hzb_band");
+    if (trc != UR_OK) return trc;
+    return ur::launch_build_hzb_band(ctx, depth, src_w, src_h, hzb_base, mips, mip_count, piece_row0, piece_rows);
+}
+
+int ur_build_hzb_tail(ur_ctx* ctx, float* hzb_base, const ur_mip_desc* mips, uint32_t mip_count)
+{
+    if (!ctx || !hzb_base || !valid_hzb_chain_below_mip0(mips, mip_count)) { set_error("ur_build_hzb_tail: bad argument"); return UR_EINVAL; }
+    const int trc = ur::check_hzb_timeout(ctx, "ur_build_hzb_tail");
+    if (trc != UR_OK) return trc;
+    return ur::launch_build_hzb_tail(ctx, hzb_base, mips, mip_count);
 }
 
 int ur_cull_indirect_args(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,

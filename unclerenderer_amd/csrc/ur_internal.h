@@ -88,6 +88,9 @@ void set_error(const char* fmt, ...);
 // kernels (one file each)
 int launch_build_hzb(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base,
                      const ur_mip_desc* mips, uint32_t mip_count);
+int launch_build_hzb_band(ur_ctx* ctx, const float* depth, uint32_t src_w, uint32_t src_h, float* hzb_base, const ur_mip_desc* mips, uint32_t mip_count,
+                          uint32_t piece_row0, uint32_t piece_rows);
+int launch_build_hzb_tail(ur_ctx* ctx, float* hzb_base, const ur_mip_desc* mips, uint32_t mip_count);
 int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds, const float* hzb_base,
                 const ur_mip_desc* mips, void* indirect_args, uint32_t* stats2, uint32_t* visible_idx,
                 uint32_t* visible_count, uint32_t index_base);

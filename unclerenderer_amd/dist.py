@@ -8,7 +8,9 @@ the GPU box, "gloo" in the CPU tests). The reference is single-GPU; this is new 
     all-gathered first, then the lists are all-gathered padded to the largest count.
   * Tonemap ahead of the gather: the band is tonemapped to R8G8B8A8 on the rank that shaded it and the
     4-byte pixels are gathered instead (allgather_rows), halving the xGMI payload.
-  * BuildHZB: replicated (every rank builds the full chain from the full depth) — no exchange.
+  * BuildHZB: replicated (every rank builds the full chain from the full depth) — no exchange; or band-sharded
+    (allgather_hzb_slices): a rank builds mips 0..4 for the 128x32 source pieces its rows own, the slices (5 contiguous runs of
+    floats per rank) are exchanged peer to peer straight into place, and every rank runs the single-workgroup tail behind it.
 """
 from __future__ import annotations
 
@@ -137,3 +139,41 @@ def allgather_visible(visible_idx: torch.Tensor, visible_count: torch.Tensor, gr
     dist.all_gather_into_tensor(recv, send, group=group)
     parts = [recv[r * cap: r * cap + counts_host[r]] for r in range(world)]
     return torch.cat(parts), sum(counts_host)
+
+
+def allgather_hzb_slices(hzb: torch.Tensor, layout, group=None, async_op: bool = False):
+    """Band-sharded Build HZB (ur_build_hzb_band): rank r has written mips 0..4 for ITS piece rows into `hzb` (the whole HZB
+    allocation, fp32); send those five runs to every peer and receive every peer's into place - 5 (N - 1) send/receive pairs per
+    rank in ONE batch (RCCL: one grouped call, every pair over the one xGMI link its two GPUs share). Slices differ in size by a
+    piece row, so this is peer-to-peer, not an all_gather of equal counts. Afterwards mips 0..4 are complete on every rank
+    (run HotPath.build_hzb_tail behind it). Returns bytes sent per peer (the added xGMI payload), and the Work when async."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0, None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    slices = [layout.band_slices(*layout.band_pieces(world, r)) for r in range(world)]
+    staged = dist.get_backend(group) == "gloo" and hzb.is_cuda
+    host = hzb.cpu() if staged else hzb  # (gloo moves host memory only: rehearsals and the CPU tests)
+    flat = host.view(-1)
+    ops = []
+    for k in range(1, world):
+        to, frm = (rank + k) % world, (rank - k) % world
+        for off, cnt in slices[rank]:
+            if cnt:
+                ops.append(dist.P2POp(dist.isend, flat[off:off + cnt], dist.get_global_rank(group, to) if group is not None else to, group))
+        for off, cnt in slices[frm]:
+            if cnt:
+                ops.append(dist.P2POp(dist.irecv, flat[off:off + cnt], dist.get_global_rank(group, frm) if group is not None else frm, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish():
+        if staged:
+            for r in range(world):
+                if r != rank:
+                    for off, cnt in slices[r]:
+                        hzb.view(-1)[off:off + cnt].copy_(flat[off:off + cnt])
+    w = _Works(reqs, finish)
+    sent = 4 * sum(c for _, c in slices[rank])
+    if async_op:
+        return sent, w
+    w.wait()
+    return sent, None

@@ -44,6 +44,18 @@ class HzbLayout:
     def mip_texels(self) -> int:
         return sum(self.mips[i].width * self.mips[i].height for i in range(self.count))
 
+    def band_pieces(self, world: int, rank: int) -> tuple[int, int]:
+        """(first piece row, piece rows) of the wide Build HZB launch that `rank` of `world` row bands builds (ur_hzb_band_pieces)."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        _lib.check(_lib.load().ur_hzb_band_pieces(self.src_h, world, rank, C.byref(a), C.byref(b)), "ur_hzb_band_pieces")
+        return int(a.value), int(b.value)
+
+    def band_slices(self, piece_row0: int, piece_rows: int) -> list[tuple[int, int]]:
+        """[(offset, count) in floats] of mips 0..4 for those piece rows (ur_hzb_band_slices): what a rank contributes to the exchange."""
+        out = (_lib.HzbSlice * 5)()
+        _lib.check(_lib.load().ur_hzb_band_slices(self.mips, self.count, piece_row0, piece_rows, out), "ur_hzb_band_slices")
+        return [(int(s.offset), int(s.count)) for s in out]
+
 
 class HotPath:
     """One ur_ctx bound to a device and a stream."""
@@ -132,6 +144,16 @@ class HotPath:
         assert depth.dtype == torch.float32 and hzb.dtype == torch.float32 and hzb.numel() >= layout.total
         assert depth.numel() == layout.src_w * layout.src_h
         _lib.check(self._L.ur_build_hzb(self._ctx, _ptr(depth), layout.src_w, layout.src_h, _ptr(hzb), layout.mips, layout.count), "ur_build_hzb")
+
+    def build_hzb_band(self, depth: torch.Tensor, hzb: torch.Tensor, layout: HzbLayout, piece_row0: int, piece_rows: int):
+        """Mips 0..4 for the 128x32 source pieces of rows [piece_row0, piece_row0 + piece_rows) only (ur_build_hzb_band)."""
+        assert depth.dtype == torch.float32 and hzb.dtype == torch.float32 and hzb.numel() >= layout.total and depth.numel() == layout.src_w * layout.src_h
+        _lib.check(self._L.ur_build_hzb_band(self._ctx, _ptr(depth), layout.src_w, layout.src_h, _ptr(hzb), layout.mips, layout.count, piece_row0, piece_rows),
+                   "ur_build_hzb_band")
+
+    def build_hzb_tail(self, hzb: torch.Tensor, layout: HzbLayout):
+        """The single-workgroup rest of the chain (mips 5.. from mip 4), behind the ranks' exchange of the band slices (ur_build_hzb_tail)."""
+        _lib.check(self._L.ur_build_hzb_tail(self._ctx, _ptr(hzb), layout.mips, layout.count), "ur_build_hzb_tail")
 
     # ---- CullIndirectArgs ----
     def cull_indirect_args(self, constants: np.ndarray, bounds: torch.Tensor, hzb, layout, indirect_args: torch.Tensor,

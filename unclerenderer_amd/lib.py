@@ -32,6 +32,11 @@ class MipDesc(C.Structure):
     _fields_ = [("offset", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+class HzbSlice(C.Structure):
+    """ur_hzb_slice: one contiguous run of floats of the HZB allocation."""
+    _fields_ = [("offset", C.c_uint32), ("count", C.c_uint32)]
+
+
 class SceneConstants(C.Structure):
     """FSceneConstants (Source/Render/RendererUtils.h:41-79)."""
     _fields_ = [
@@ -113,6 +118,7 @@ UR_FRAME_HZB_TAIL_WITH_LIGHTING = 0x2000
 UR_FRAME_HZB_WITH_LIGHTING = 0x4000
 UR_FRAME_TIME_LIGHTING_RECORD_COST = 0x8000
 UR_FRAME_TIME_LIGHTING_KERNEL = 0x10000
+UR_FRAME_HZB_SHARD = 0x20000
 UR_FRAME_DEFAULT = UR_FRAME_INDIRECT_DRAW | UR_FRAME_HZB | UR_FRAME_DEPTH_PREPASS | UR_FRAME_SHADOWS | UR_FRAME_SKY
 
 assert C.sizeof(SceneConstants) == 608 and C.sizeof(SkyConstants) == 240
@@ -140,6 +146,10 @@ SIGNATURES = {
     "ur_version": (C.c_char_p, []),
     "ur_hzb_layout": (_U32, [_U32, _U32, C.POINTER(MipDesc), C.POINTER(_U32)]),
     "ur_build_hzb": (C.c_int, [_VP, _VP, _U32, _U32, _VP, C.POINTER(MipDesc), _U32]),
+    "ur_hzb_band_pieces": (C.c_int, [_U32, _U32, _U32, C.POINTER(_U32), C.POINTER(_U32)]),
+    "ur_hzb_band_slices": (C.c_int, [C.POINTER(MipDesc), _U32, _U32, _U32, C.POINTER(HzbSlice)]),
+    "ur_build_hzb_band": (C.c_int, [_VP, _VP, _U32, _U32, _VP, C.POINTER(MipDesc), _U32, _U32, _U32]),
+    "ur_build_hzb_tail": (C.c_int, [_VP, _VP, C.POINTER(MipDesc), _U32]),
     "ur_cull_indirect_args": (C.c_int, [_VP, C.POINTER(_U32), _VP, _VP, C.POINTER(MipDesc), _VP, _VP, _VP, _VP]),
     "ur_cull_indirect_args_ex": (C.c_int, [_VP, C.POINTER(_U32), _VP, _VP, C.POINTER(MipDesc), _VP, _VP, _VP, _VP, _U32]),
     "ur_env_cube_texels": (C.c_size_t, [_U32, _U32]),
