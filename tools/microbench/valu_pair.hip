@@ -1,7 +1,7 @@
 // What shares a VALU issue slot on gfx950? Streams of two independent v_fma_f32 chains per wave (which pair: ~2.4 cycles per
-// instruction per SIMD, tools/microbench/valu_rate5.hip) with other instructions BETWEEN the two halves of a pair: a scalar ALU op,
+// instruction per SIMD, tools/microbench/valu_rate.hip, table 5) with other instructions BETWEEN the two halves of a pair: a scalar ALU op,
 // an LDS read, a side-pipe VALU op; and dependent / independent neighbours in both orders. Every scalar register the asm touches
-// is an operand and SCC is declared clobbered (valu_rate3's k_mix_fma_salu clobbered s4/s5 and SCC behind the compiler's back: the
+// is an operand and SCC is declared clobbered (table 3.s k_mix_fma_salu clobbered s4/s5 and SCC behind the compiler's back: the
 // loop's own compare lives in SCC, and the kernel never ended).
 #include <hip/hip_runtime.h>
 #include <cstdio>

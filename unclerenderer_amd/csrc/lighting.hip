@@ -705,7 +705,7 @@ __device__ __forceinline__ float vreg(float uniform)
 }
 
 // fp16 halves of a packed dword -> fp32 behind an opaque conversion: hipcc would otherwise fold the conversions into
-// v_fma_mix_f32 / SDWA forms, which hold the VALU issue port for 4-6 cycles on gfx950 (tools/microbench/valu_rate4.hip)
+// v_fma_mix_f32 / SDWA forms, which hold the VALU issue port for 4-6 cycles on gfx950 (tools/microbench/valu_rate.hip, table 4)
 // where a plain v_cvt on the side pipe overlaps with the FMAs around it.
 __device__ __forceinline__ float h2f_lo(uint32_t w)
 {
@@ -727,7 +727,7 @@ __device__ __forceinline__ float gt_step(float cmpBig, float t, float negBig /* 
 // Wave-uniform conditions as SGPR integers. A `bool` that is defined in one basic block and tested or negated in another is a
 // lane mask to hipcc, and every such use goes through a VGPR: `v_cndmask_b32 v, 0, 1, mask` + `v_cmp_ne_u32 mask', 1, v` to
 // negate a mask that `s_not_b64` would negate — two vector instructions of the 4-cycle class that cannot share an issue slot
-// with a neighbour (tools/microbench/valu_rate3/4.hip). The loop had four such pairs per iteration; with the ballot taken where
+// with a neighbour (tools/microbench/valu_rate.hip, tables 3 and 4). The loop had four such pairs per iteration; with the ballot taken where
 // the comparison is made and a 32-bit scalar crossing the blocks there are none (profiles/r03_lighting_diet.txt: -1.2 us).
 __device__ __forceinline__ uint32_t flag_any(bool pred)
 {
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     const float rowh = (float)row + 0.5f; // ndc.y = (py + 0.5) * 2/H - 1 with py = row0 + 4 ty + row summed exactly: a band and the whole frame agree bit for bit
     const float negBig = vreg(-0x1p126f);
     // Launch constants of the FMA-dense parts as VGPR operands: two neighbouring VALU instructions that both read an SGPR
-    // cannot share an issue slot (tools/microbench/valu_rate4.hip), and a VOP3 reads one SGPR at most.
+    // cannot share an issue slot (tools/microbench/valu_rate.hip, table 4), and a VOP3 reads one SGPR at most.
     float R[9], WC[3], shC[3], shT[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = vreg(p.hot.R[k]);
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             f2_t prexy;
             float prez;
             {
-                // The 24 mixed-precision FMAs below cannot share an issue slot with anything (tools/microbench/valu_rate4.hip):
+                // The 24 mixed-precision FMAs below cannot share an issue slot with anything (tools/microbench/valu_rate.hip, table 4):
                 // a weight computed BETWEEN two of them costs a slot of its own, computed next to another weight half of one.
                 const float s0 = 1.0f - fl;
                 float a00, a10, a01, a11, b00, b10, b01, b11;
