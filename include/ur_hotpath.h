@@ -111,7 +111,7 @@ typedef struct ur_sky_constants {
 /* Read-only side tables of the lighting pass (t3..t5 of DeferredLighting.hlsl:11-16). All device. */
 typedef struct ur_lighting_tables {
     const float* shadow_map;       /* ShadowMapSize.x * ShadowMapSize.y R32F; may be NULL iff ShadowStrength <= 0 */
-    const ur_half4* env_cube;      /* what ur_stage_env_cube() wrote: the bordered faces of every mip, then the same faces as row pairs */
+    const ur_half4* env_cube;      /* what ur_stage_env_cube() wrote: the bordered faces of every mip, then the same faces as RGB row pairs */
     uint32_t env_base_size;        /* edge of mip 0 (256 for Assets/Textures/output_pmrem.dds) */
     uint32_t env_mip_count;        /* mips present in env_cube (9) */
     const uint16_t* brdf_lut_rg16; /* lut_width * lut_height texels, 2 x UNORM16 each (PreintegratedGF.dds) */
@@ -270,15 +270,16 @@ int ur_cull_indirect_args_ex(ur_ctx* ctx, const uint32_t* constants, const ur_fl
 
 /* ---- DeferredLighting / SkyAtmosphere ---------------------------------------------------------- */
 
-/* Number of half4 texels ur_stage_env_cube() writes for (base_size, mip_count): the bordered faces, 6 (N+2)^2 per mip, followed
- * by the same texels as row pairs, 12 (N+2)(N+1) per mip; 0 on bad arguments. */
+/* Number of half4 units (8 bytes) ur_stage_env_cube() writes for (base_size, mip_count): the bordered faces, 6 (N+2)^2 texels per mip,
+ * followed by the same texels as RGB row pairs, 6 (N+2)(N+1) entries of 12 bytes per mip; 0 on bad arguments. */
 size_t ur_env_cube_texels(uint32_t base_size, uint32_t mip_count);
 /* Stage an RGBA16F cube in DDS order (face-major, mips inner; TextureLoader.cpp:276-315) from HOST
  * memory into the device layout the lighting kernel samples: mip-major, 6 faces per mip, each face
  * (N+2)x(N+2) with a one-texel border holding the seamless neighbours from the adjacent faces; behind all mips the same faces
- * once more as ROW PAIRS (entry (f, j, i) = {texel (i, j), texel (i, j+1)}, 16 bytes, pair-rows contiguous), so that a 2x2
- * bilinear footprint is 32 contiguous bytes: the layout the streaming kernel gathers its prefiltered taps from.
- * dst_device must hold ur_env_cube_texels() texels. Synchronous (setup time, like the DDS upload). */
+ * once more as RGB ROW PAIRS (entry (f, j, i) = {R G B of texel (i, j), R G B of texel (i, j+1)}, 12 bytes, pair-rows contiguous;
+ * the shader never samples the cube's alpha: DeferredLighting.hlsl:82,86), so that a 2x2 bilinear footprint is 24 contiguous
+ * bytes: the layout the streaming kernel gathers its prefiltered taps from.
+ * dst_device must hold ur_env_cube_texels() units. Synchronous (setup time, like the DDS upload). */
 int ur_stage_env_cube(ur_ctx* ctx, const ur_half4* src_host, uint32_t base_size, uint32_t mip_count,
                       ur_half4* dst_device);
 

@@ -55,7 +55,7 @@ def test_hzb_layout_matches_create_hzb_resources(urlib):
 
 def test_env_cube_texels(urlib):
     e = [max(1, 256 >> m) + 2 for m in range(9)]
-    assert urlib.ur_env_cube_texels(256, 9) == 6 * sum(x * x for x in e) + 12 * sum(x * (x - 1) for x in e)  # bordered faces + row pairs
+    assert urlib.ur_env_cube_texels(256, 9) == 6 * sum(x * x for x in e) + 9 * sum(x * (x - 1) for x in e)  # bordered faces + RGB row pairs (12-byte entries, in 8-byte units)
     assert urlib.ur_env_cube_texels(0, 9) == 0 and urlib.ur_env_cube_texels(256, 17) == 0
 
 

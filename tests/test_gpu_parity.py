@@ -359,15 +359,17 @@ def test_stage_env_cube_matches_folding_rule(hotpath, oracle):
     ref = oracle.stage_env_cube(env, 16, 5).reshape(-1, 4)
     nb = ref.shape[0]
     assert np.array_equal(got[:nb], ref)  # the bordered faces
-    # behind them the same faces as row pairs: entry (f, j, i) = {texel (i, j), texel (i, j + 1)}
-    off, boff = nb, 0
+    # behind them the same faces as RGB row pairs: entry (f, j, i) = {R G B of texel (i, j), R G B of texel (i, j + 1)}, 12 bytes
+    rgb = got[nb:].reshape(-1)  # uint16 stream
+    off, boff = 0, 0
     for m in range(5):
         E = max(1, 16 >> m) + 2
-        faces = ref[boff:boff + 6 * E * E].reshape(6, E, E, 4)
-        pairs = np.stack([faces[:, :-1], faces[:, 1:]], axis=3)  # (6, E-1, E, 2, 4)
-        assert np.array_equal(got[off:off + 12 * E * (E - 1)], pairs.reshape(-1, 4)), m
-        off += 12 * E * (E - 1); boff += 6 * E * E
-    assert off == got.shape[0]
+        faces = ref[boff:boff + 6 * E * E].reshape(6, E, E, 4)[..., :3]
+        pairs = np.stack([faces[:, :-1], faces[:, 1:]], axis=3)  # (6, E-1, E, 2, 3)
+        n = 6 * E * (E - 1) * 6
+        assert np.array_equal(rgb[off:off + n], pairs.reshape(-1)), m
+        off += n; boff += 6 * E * E
+    assert off == rgb.size
 
 
 @pytest.mark.parametrize("case", ["sheared_view", "scaled_view", "camera_elsewhere", "shadow_2x2", "shadow_1x1", "shadow_2x5"])

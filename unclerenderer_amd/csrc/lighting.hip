@@ -151,6 +151,8 @@ struct float3u { float x, y, z; };       // 12 bytes loaded from a 4-byte-aligne
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x3_t __attribute__((ext_vector_type(3)));
 typedef u32x4_t u32x4_a8 __attribute__((aligned(8)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef u32x3_t u32x3_a4 __attribute__((aligned(4)));
 typedef f32x3_t f32x3_a4 __attribute__((aligned(4)));
 template <>
 __device__ __forceinline__ uint4u ld<uint4u>(const void* base, uint32_t byte_offset)
@@ -744,12 +746,13 @@ __device__ __forceinline__ uint32_t flag_all(bool pred) // (every lane of the wa
     return r;
 }
 
-// Per-mip constants of the cube's ROW-PAIR section (ur_stage_env_cube): N, the entries per pair-row E = N + 2, the entries per face
-// E (E - 1), and the mip's first entry counted from the start of the buffer - all in 16-byte entries, as floats (exact below 2^24).
-struct __attribute__((aligned(16))) MipEntry { float Nf, Ef, EEf, offf; };
+// Per-mip constants of the cube's RGB ROW-PAIR section (ur_stage_env_cube: 12-byte entries): N, and - in BYTES from the start of the
+// buffer, as floats (exact below 2^24) - a pair-row (12 E, E = N + 2), a face (12 E (E - 1)) and the mip's first entry.
+struct __attribute__((aligned(16))) MipEntry { float Nf, rowBf, faceBf, offBf; };
 
 // input-only "these registers are needed here": hipcc puts the s_waitcnt of pending loads in front of the statement
-__device__ __forceinline__ void need(const u32x4_t& a, const u32x4_t& b, const u32x4_t& c, const u32x4_t& d)
+template <class V>
+__device__ __forceinline__ void need(const V& a, const V& b, const V& c, const V& d)
 {
     asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d));
 }
@@ -1002,7 +1005,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 bordered += 6u * e * e;
                 if (k < m) before += 6u * e * (e - 1u);
             }
-            mipT[threadIdx.x] = MipEntry{(float)N, (float)E, (float)(E * (E - 1u)), (float)(bordered / 2u + before)};
+            mipT[threadIdx.x] = MipEntry{(float)N, (float)(12u * E), (float)(12u * E * (E - 1u)), (float)(bordered * 8u + before * 12u)};
         }
 #pragma unroll
         for (uint32_t k = 0; k < kLutTrips; ++k) {
@@ -1157,24 +1160,24 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             f2_t uvR;
             uvR = f2(fmaf(__builtin_amdgcn_cubesc(Rw.x, Rw.y, Rw.z), invR, 0.5f), fmaf(__builtin_amdgcn_cubetc(Rw.x, Rw.y, Rw.z), invR, 0.5f));
             const void* env = p.hot.env;
-            u32x4_t p0a, p0b, p1a, p1b;
+            u32x3_t p0a, p0b, p1a, p1b;
             f2_t f0, f1; // (fx, fy) of the two mips
             {
                 const f2_t xy = f2(fmaf(uvR.x, e0.x, 0.5f), fmaf(uvR.y, e0.x, 0.5f)); // bordered coordinates in [0.5, N + 0.5]
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
                 f0 = f2(xy.x - i0, xy.y - j0);
-                // row-pair section: the footprint's 32 contiguous bytes {(i0, j0), (i0, j0 + 1)} {(i0 + 1, j0), (i0 + 1, j0 + 1)}
-                const uint32_t o = (uint32_t)(fmaf(faceR, e0.z, fmaf(j0, e0.y, i0)) + e0.w) * 16u;
-                p0a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
-                p0b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + 16u));
+                // RGB row-pair section: the footprint's 24 contiguous bytes {(i0, j0), (i0, j0 + 1)} {(i0 + 1, j0), (i0 + 1, j0 + 1)}
+                const uint32_t o = (uint32_t)fmaf(faceR, e0.z, fmaf(j0, e0.y, fmaf(i0, 12.0f, e0.w)));
+                p0a = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + o);
+                p0b = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + (o + 12u));
             }
             {
                 const f2_t xy = f2(fmaf(uvR.x, e1.x, 0.5f), fmaf(uvR.y, e1.x, 0.5f));
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
                 f1 = f2(xy.x - i0, xy.y - j0);
-                const uint32_t o = (uint32_t)(fmaf(faceR, e1.z, fmaf(j0, e1.y, i0)) + e1.w) * 16u;
-                p1a = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + o);
-                p1b = *reinterpret_cast<const UR_GLOBAL u32x4_a8*>((const UR_GLOBAL char*)env + (o + 16u));
+                const uint32_t o = (uint32_t)fmaf(faceR, e1.z, fmaf(j0, e1.y, fmaf(i0, 12.0f, e1.w)));
+                p1a = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + o);
+                p1b = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + (o + 12u));
             }
             const float faceN = __builtin_amdgcn_cubeid(Nxy.x, Nxy.y, Nz);
             const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nxy.x, Nxy.y, Nz)));
@@ -1313,15 +1316,16 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
                 b10 = b0 * fx1; b00 = b0 - b10; b11 = b1 * fx1; b01 = b1 - b11;
                 asm volatile("" : "+v"(a00), "+v"(a10), "+v"(a01), "+v"(a11), "+v"(b00), "+v"(b10), "+v"(b01), "+v"(b11));
                 float x, y, z;
-                // (p.a = {texel (i0, j0), texel (i0, j0 + 1)}, p.b = the same of column i0 + 1; summed in the order 00, 10, 01, 11)
+                // (p.a = {R G | B R' | G' B'} of column i0: texel (i0, j0) then texel (i0, j0 + 1); p.b the same of column i0 + 1; summed
+                // in the order 00, 10, 01, 11)
                 x = mul_lo(p0a.x, a00); y = mul_hi(p0a.x, a00); z = mul_lo(p0a.y, a00);
                 x = mix_lo(x, p0b.x, a10); y = mix_hi(y, p0b.x, a10); z = mix_lo(z, p0b.y, a10);
-                x = mix_lo(x, p0a.z, a01); y = mix_hi(y, p0a.z, a01); z = mix_lo(z, p0a.w, a01);
-                x = mix_lo(x, p0b.z, a11); y = mix_hi(y, p0b.z, a11); z = mix_lo(z, p0b.w, a11);
+                x = mix_hi(x, p0a.y, a01); y = mix_lo(y, p0a.z, a01); z = mix_hi(z, p0a.z, a01);
+                x = mix_hi(x, p0b.y, a11); y = mix_lo(y, p0b.z, a11); z = mix_hi(z, p0b.z, a11);
                 x = mix_lo(x, p1a.x, b00); y = mix_hi(y, p1a.x, b00); z = mix_lo(z, p1a.y, b00);
                 x = mix_lo(x, p1b.x, b10); y = mix_hi(y, p1b.x, b10); z = mix_lo(z, p1b.y, b10);
-                x = mix_lo(x, p1a.z, b01); y = mix_hi(y, p1a.z, b01); z = mix_lo(z, p1a.w, b01);
-                x = mix_lo(x, p1b.z, b11); y = mix_hi(y, p1b.z, b11); z = mix_lo(z, p1b.w, b11);
+                x = mix_hi(x, p1a.y, b01); y = mix_lo(y, p1a.z, b01); z = mix_hi(z, p1a.z, b01);
+                x = mix_hi(x, p1b.y, b11); y = mix_lo(y, p1b.z, b11); z = mix_hi(z, p1b.z, b11);
                 prexy = f2(x, y); prez = z;
                 if (!IRR_LDS) {
                     CubeTaps t;
@@ -1690,12 +1694,13 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
     // ---- streaming kernel when the band is a whole number of 16-pixel tile columns; the per-tile kernel otherwise -----------
     const int use_stream = ctx->opt.lighting_stream; // UR_OPT_LIGHTING_STREAM
     bool streamed = false;
-    // (the streaming kernel addresses the staged cube in fp32: texel indices must stay below 2^24, i.e. base sizes up to 1024)
+    // (the streaming kernel addresses the staged cube's RGB row-pair section in fp32 BYTE offsets, which must stay below 2^24: base
+    // sizes up to 256; bigger cubes take the per-tile kernel)
     uint64_t env_texels = 0;
     if (mode != UR_MODE_SKY)
-        for (uint32_t m = 0; m < p.envMips; ++m) { // (the gathers address the row-pair section behind the bordered mips, in 16-byte entries)
+        for (uint32_t m = 0; m < p.envMips; ++m) {
             const uint64_t e = (uint64_t)std::max(1u, p.envBase >> m) + 2u;
-            env_texels += 6u * e * e / 2u + 6u * e * (e - 1u);
+            env_texels += 6u * e * e * 8u + 6u * e * (e - 1u) * 12u;
         }
     const uint64_t n_tiles = (uint64_t)(w / 16u) * ((rows + 3u) / 4u);
     const uint64_t magic_err = w >= 16u ? ((1ull << 32) / (w / 16u) + 1ull) * (w / 16u) - (1ull << 32) : 0;

@@ -436,8 +436,8 @@ size_t ur_env_cube_texels(uint32_t base_size, uint32_t mip_count)
     size_t n = 0;
     for (uint32_t m = 0; m < mip_count; ++m) {
         const size_t e = (base_size >> m > 1u ? base_size >> m : 1u) + 2u;
-        n += 6u * e * e;            // the bordered faces
-        n += 6u * (e - 1u) * e * 2u; // the same texels once more as row PAIRS (see ur_stage_env_cube)
+        n += 6u * e * e;        // the bordered faces
+        n += 9u * (e - 1u) * e; // the same texels once more as RGB row pairs: 6 (e - 1) e entries of 12 bytes = 9 (e - 1) e half4 units
     }
     return n;
 }
@@ -465,22 +465,24 @@ int ur_stage_env_cube(ur_ctx* ctx, const ur_half4* src, uint32_t base, uint32_t 
                 }
         off += (size_t)6 * E * E;
     }
-    // Second section, behind all bordered mips: every mip once more as ROW PAIRS. Entry (f, j, i), j in [0, E-2], is the 16 bytes
-    // {texel (i, j), texel (i, j + 1)} of the bordered face, entries of a pair-row contiguous: the 2x2 bilinear footprint at
-    // (i, j) is the 32 bytes at entry ((f (E-1) + j) E + i) - two 16-byte loads that almost always fall into ONE cache line
-    // where the bordered layout's two rows are two lines. The streaming lighting kernel gathers its prefiltered taps here.
+    // Second section, behind all bordered mips: every mip once more as RGB ROW PAIRS. Entry (f, j, i), j in [0, E-2], is the 12 bytes
+    // {R G B of texel (i, j), R G B of texel (i, j + 1)} of the bordered face (the alpha channel is never sampled:
+    // DeferredLighting.hlsl:82,86 take .rgb), entries of a pair-row contiguous: the 2x2 bilinear footprint at (i, j) is the 24
+    // bytes at entry ((f (E-1) + j) E + i) - two 12-byte loads that almost always fall into ONE cache line where the bordered
+    // layout's two rows are two lines and two 16-byte loads. The streaming lighting kernel gathers its prefiltered taps here.
     {
-        size_t boff = 0;
+        uint16_t* rgb = reinterpret_cast<uint16_t*>(out.data() + off);
+        size_t boff = 0, e = 0;
         for (uint32_t m = 0; m < mip_count; ++m) {
             const size_t E = (size_t)(base >> m > 1u ? base >> m : 1u) + 2u;
             for (size_t f = 0; f < 6; ++f)
                 for (size_t j = 0; j + 1 < E; ++j)
                     for (size_t i = 0; i < E; ++i) {
-                        const size_t e = off + (((f * (E - 1) + j) * E) + i) * 2u;
-                        out[e] = out[boff + (f * E + j) * E + i];
-                        out[e + 1] = out[boff + (f * E + j + 1) * E + i];
+                        const ur_half4& t0 = out[boff + (f * E + j) * E + i];
+                        const ur_half4& t1 = out[boff + (f * E + j + 1) * E + i];
+                        rgb[e++] = t0.x; rgb[e++] = t0.y; rgb[e++] = t0.z;
+                        rgb[e++] = t1.x; rgb[e++] = t1.y; rgb[e++] = t1.z;
                     }
-            off += 6u * (E - 1) * E * 2u;
             boff += 6u * E * E;
         }
     }
