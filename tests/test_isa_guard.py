@@ -192,7 +192,7 @@ def test_dma_ordering_protocol_in_the_isa(lighting_co, kernel):
 def test_the_guard_notices_a_missing_wait(lighting_co):
     """The walk is not vacuous: with the vmcnt(0) in front of the loop's DMAs deleted from the listing it must object."""
     ins, labels = _disassemble(lighting_co, HOT)
-    dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4")]
+    dma = [i for i, t in enumerate(ins) if _is_tile_dma(t)]
     cut = list(ins)
     for a in dma:
         for j in range(a - 1, max(a - 120, 0), -1):
@@ -203,10 +203,16 @@ def test_the_guard_notices_a_missing_wait(lighting_co):
         _check_protocol(cut, labels, HOT)
 
 
+def _is_tile_dma(t: str) -> bool:
+    """The two DMA instructions of a G-buffer tile (tile_dma_at: `... nt` then `... offset:1024`). The prologue's one-off DMA of the
+    cube's small mips into LDS (dma16: neither modifier) is waited for ahead of the loop and is not part of the protocol."""
+    return t.startswith("global_load_lds_dwordx4") and (" nt" in t or "offset:1024" in t)
+
+
 def _check_protocol(ins, labels, kernel):
     pred = _predecessors(ins, labels)
     barriers = [i for i, t in enumerate(ins) if t.startswith("s_barrier")]
-    dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4")]
+    dma = [i for i, t in enumerate(ins) if _is_tile_dma(t)]
     assert barriers and len(dma) >= 8 and len(dma) % 2 == 0
     for a, b in zip(dma[0::2], dma[1::2]):
         assert b == a + 1, "the two DMA instructions of a tile (A|B and HDR|C|depth) are issued back to back"
@@ -247,30 +253,28 @@ RIDE_ALL = "lighting_stream_kernelILi2ELb1ELb1ELi16ELb1E"  # the same kernel wit
 
 @pytest.mark.parametrize("kernel", [HOT, RIDE_ALL, "lighting_stream_kernelILi0ELb1ELb1ELi16ELb0E"])
 def test_no_spill_traffic_inside_the_loop(lighting_co, kernel):
-    """The persistent loop's hot body = from the loop head (the lowest target of a backward branch that has a tile DMA inside its
-    span, the branches that span nearly the whole kernel aside) to the last such branch that starts at the head; the run-time
-    claim path (dyn_claim, cold) is laid out behind it and jumps back in. No SGPR-spill STORE (v_writelane) and no scratch access
-    anywhere on the cycle; no spill RELOAD (v_readlane) in the hot body of the bench kernel, at most two in the every-wave-walks
-    variant (one extra scalar of its pre-loop code lives across the loop)."""
+    """The persistent loop = the strongly connected component of the control-flow graph that holds the tile DMAs (the shading body,
+    its all-sky sub-loop and, laid out behind it, the cold run-time claim path dyn_claim, which jumps back in). No SGPR-spill STORE
+    (v_writelane) and no scratch access anywhere on it; spill RELOADS (v_readlane) only the few the cold claim path needs - the
+    bench kernel has eight there and none in the shading body; the every-wave-walks variant keeps one extra scalar of its pre-loop
+    code across the loop (two more reloads). A compiler that starts spilling in the shading body trips the count."""
     ins, labels = _disassemble(lighting_co, kernel)
-    dmas = [i for i, t in enumerate(ins) if t.startswith("global_load_lds_dwordx4")]
-    loops = []
-    for i, t in enumerate(ins):
-        op = t.split()[0]
-        if op.startswith(("s_cbranch", "s_branch")):
-            tgt = labels.get(t.split()[-1])
-            if tgt is not None and tgt < i and any(tgt <= d <= i for d in dmas) and i - tgt < len(ins) // 2:
-                loops.append((tgt, i))
-    assert loops, "no backward branch around a tile DMA: where is the persistent loop?"
-    head = min(a for a, _ in loops)
-    body_end = max(b for a, b in loops if a == head)
-    cycle_end = max(b for _, b in loops)
-    assert body_end - head > 300, (head, body_end)  # the shading loop, not a sub-loop of it
-    spill_ops = ("v_writelane", "scratch_", "buffer_store", "buffer_load")
-    bad = [t for t in ins[head:cycle_end + 1] if t.startswith(spill_ops)]
+    pred = _predecessors(ins, labels)
+    dma = [i for i, t in enumerate(ins) if _is_tile_dma(t)]
+    on_cycle = _cycle_members(pred, len(ins))
+    loop_dma = [i for i in dma[0::2] if i in on_cycle]
+    assert len(loop_dma) >= 2
+    loop = _component_of(pred, loop_dma[0], on_cycle)
+    assert len(loop) > 600, len(loop)  # the shading loop, not a sub-loop of it
+    bad = [ins[i] for i in sorted(loop) if ins[i].startswith(("v_writelane", "scratch_", "buffer_store", "buffer_load"))]
     assert not bad, bad[:8]
-    reloads = [t for t in ins[head:body_end + 1] if t.startswith("v_readlane")]
-    assert len(reloads) <= (2 if kernel == RIDE_ALL else 0), reloads
+    reloads = [(i, ins[i]) for i in sorted(loop) if ins[i].startswith("v_readlane")]
+    assert len(reloads) <= (10 if kernel == RIDE_ALL else 8), reloads
+    # ... and none of them in front of the shading body's gathers: the reloads sit behind the last cube / shadow gather of the listing
+    gathers = [i for i in sorted(loop) if re.match(r"global_load_dwordx3\b", ins[i])]
+    assert gathers
+    if kernel != RIDE_ALL:
+        assert all(i > max(gathers) for i, _ in reloads), (reloads, max(gathers))
 
 
 def test_the_product_kernel_source_carries_no_variant_switches():

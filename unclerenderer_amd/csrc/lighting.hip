@@ -54,6 +54,10 @@ struct StreamHot {
     const float* shadow;
     void* hdr;
     float skyDepthMax;   // no sphere depth of the frame exceeds it
+    // the cube's small mips in LDS: a pixel whose prefiltered level is >= cubeLdsLevel takes both footprints from the workgroup's
+    // copy of the RGB row-pair entries of mips [cubeLdsLevel, last] (byte address = global byte offset - cubeLdsAdj)
+    float cubeLdsLevel;  // (16.0: nothing is in LDS)
+    uint32_t cubeLdsBase, cubeLdsBytes; // where those mips' entries start in the staged buffer (bytes), and how many bytes they are
     // read once per wave into VGPRs
     float R[9];          // (float3x3)ViewInverse, row-major
     float Lw[3];         // light direction, world space
@@ -608,6 +612,8 @@ constexpr uint32_t kLdsHzb = kLdsDyn + kDynSlots * 4;               // 80 floats
 constexpr uint32_t kLdsLut = kLdsHzb + 16 * 80 * 4;                 // (kLutW + 2) x (kLutH + 2) float2
 constexpr uint32_t kLdsTiles = kLdsLut + kLutE * (kLutH + 2) * 8;   // per wave: 2 x 2 KB
 constexpr uint32_t kTileBytes = 2048;                               // A 512 | B 512 | HDR 512 | C 256 | depth 256
+constexpr uint32_t kLdsCubeBytes = 32768;                           // behind the waves' tile buffers: RGB row-pair entries of the cube's small mips
+                                                                    // (the shipped 256^2 cube: mips 4..8 = 31 968 bytes)
 static_assert(kLdsTiles % 16 == 0, "tile buffers are 16-byte aligned");
 
 __device__ __forceinline__ uint32_t lds_address(const void* p)
@@ -956,6 +962,17 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
 
 
     if (have0) tile_prefetch<MODE>(&p, p.hot.W, p.hot.rows, src, lane, tx, ty, bufBase);
+    // The cube's small mips -> LDS by DMA, 1-KB pieces dealt over the waves (the shipped cube: 32 pieces, two per wave), behind the
+    // first tile: rough pixels then take their two prefiltered footprints from LDS instead of through the L1 (four gathers fewer).
+    const uint32_t cubeLds = __builtin_amdgcn_readfirstlane(lds_address(smem + kLdsTiles + WPB * (2u * kTileBytes)));
+    const uint32_t cubeLdsAdj = p.hot.cubeLdsBase - cubeLds; // LDS byte address of an entry = its byte offset in the staged buffer - this
+    {
+        const uint32_t nb = p.hot.cubeLdsBytes; // uniform; 0: off
+        for (uint32_t pc = wave; pc * 1024u < nb; pc += WPB) { // uniform trip count per wave
+            const uint32_t at = min(pc * 1024u + lane * 16u, nb - 16u); // (the last piece re-reads the section's last 16 bytes past its end)
+            dma16(reinterpret_cast<const char*>(p.hot.env) + p.hot.cubeLdsBase + at, cubeLds + pc * 1024u);
+        }
+    }
     // per-lane part of the pixel's NDC (the tile origin is added per iteration), and the few uniforms that appear as the
     // SECOND scalar operand of an FMA
     const float ndcxL = fmaf((float)col, p.invW2, 0.5f * p.invW2 - 1.0f);
@@ -972,7 +989,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     }
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
-        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
+        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; work[3] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
         if (p.bal.poolChunks != 0u && threadIdx.x < kDynSlots) { // uniform: the run-time part of the tile schedule (struct Balance)
             // this workgroup's claim word q serves workgroups [8q, 8q + 8): its share of the pool is chunks [P0, P1); the first
             // `lookahead` chunks of each of its nq workgroups are pre-assigned, the rest is claimed
@@ -1024,6 +1041,9 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // (that wait covered this wave's pieces of the cube's small mips, issued ahead of the barrier: count the wave in; a pixel takes
+    // the LDS copy only once all WPB waves are counted, the global section - the same bytes - until then)
+    if (lane == 0) __hip_atomic_fetch_add(work + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
     // ---- a held-back HZB chain's wide launch rides along: this workgroup's pieces g, g + groups, ... before the tile loop,
     //      dealt over its last `walkers` waves. The waves that walk none join the tile loop at once and the LDS work counter
@@ -1162,22 +1182,31 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
             const void* env = p.hot.env;
             u32x3_t p0a, p0b, p1a, p1b;
             f2_t f0, f1; // (fx, fy) of the two mips
+            uint32_t o0, o1; // byte offsets of the two footprints in the staged cube's RGB row-pair section
             {
                 const f2_t xy = f2(fmaf(uvR.x, e0.x, 0.5f), fmaf(uvR.y, e0.x, 0.5f)); // bordered coordinates in [0.5, N + 0.5]
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
                 f0 = f2(xy.x - i0, xy.y - j0);
-                // RGB row-pair section: the footprint's 24 contiguous bytes {(i0, j0), (i0, j0 + 1)} {(i0 + 1, j0), (i0 + 1, j0 + 1)}
-                const uint32_t o = (uint32_t)fmaf(faceR, e0.z, fmaf(j0, e0.y, fmaf(i0, 12.0f, e0.w)));
-                p0a = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + o);
-                p0b = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + (o + 12u));
+                // the footprint's 24 contiguous bytes {(i0, j0), (i0, j0 + 1)} {(i0 + 1, j0), (i0 + 1, j0 + 1)}
+                o0 = (uint32_t)fmaf(faceR, e0.z, fmaf(j0, e0.y, fmaf(i0, 12.0f, e0.w)));
             }
             {
                 const f2_t xy = f2(fmaf(uvR.x, e1.x, 0.5f), fmaf(uvR.y, e1.x, 0.5f));
                 const float i0 = floorf(xy.x), j0 = floorf(xy.y);
                 f1 = f2(xy.x - i0, xy.y - j0);
-                const uint32_t o = (uint32_t)fmaf(faceR, e1.z, fmaf(j0, e1.y, fmaf(i0, 12.0f, e1.w)));
-                p1a = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + o);
-                p1b = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + (o + 12u));
+                o1 = (uint32_t)fmaf(faceR, e1.z, fmaf(j0, e1.y, fmaf(i0, 12.0f, e1.w)));
+            }
+            // rough pixels (both mips among the cube's small ones) read the workgroup's LDS copy once every wave's pieces have landed
+            if (lvl >= p.hot.cubeLdsLevel && __hip_atomic_load(work + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)WPB) {
+                typedef __attribute__((address_space(3))) const u32x3_a4* LdsRgb;
+                const uint32_t l0 = o0 - cubeLdsAdj, l1 = o1 - cubeLdsAdj;
+                p0a = *(LdsRgb)(uintptr_t)l0; p0b = *(LdsRgb)(uintptr_t)(l0 + 12u);
+                p1a = *(LdsRgb)(uintptr_t)l1; p1b = *(LdsRgb)(uintptr_t)(l1 + 12u);
+            } else {
+                p0a = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + o0);
+                p0b = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + (o0 + 12u));
+                p1a = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + o1);
+                p1b = *reinterpret_cast<const UR_GLOBAL u32x3_a4*>((const UR_GLOBAL char*)env + (o1 + 12u));
             }
             const float faceN = __builtin_amdgcn_cubeid(Nxy.x, Nxy.y, Nz);
             const float invN = rcp(fabsf(__builtin_amdgcn_cubema(Nxy.x, Nxy.y, Nz)));
@@ -1450,7 +1479,7 @@ template <int MODE, bool SHADOWS, bool IRR_LDS, int WPB>
 int launch_stream_wpb(ur_ctx* ctx, LightingParams p /* by value: the tile walk is filled in here */)
 {
     typedef void (*kernel_t)(LightingParams, ur::HzbTail, HzbRide);
-    constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes;
+    constexpr uint32_t lds = kLdsTiles + WPB * 2u * kTileBytes + kLdsCubeBytes;
     p.timeline = ur::next_timeline_pair(ctx);
     // MaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: one flag per instantiation and device
     static bool attr_set[2][64] = {};
@@ -1760,6 +1789,24 @@ int launch_lighting(ur_ctx* ctx, const ur_scene_constants* S, const ur_sky_const
             {   // largest sphere depth of the frame: (Near/R) * |(vx, vy, 1)| at the ndc corner, with a margin of a few ulp
                 const double vx = p.skyInvP11, vy = p.skyInvP22;
                 h.skyDepthMax = (float)(p.skyNearOverR * std::sqrt(vx * vx + vy * vy + 1.0) * (1.0 + 1e-5));
+            }
+            {   // the cube's smallest mips whose RGB row-pair entries fit the workgroup's LDS copy (the shipped cube: mips 4..8)
+                uint32_t first = p.envMips;
+                uint64_t bytes = 0, bordered = 0, before = 0;
+                for (uint32_t m = p.envMips; m-- > 0;) {
+                    const uint64_t e = (uint64_t)std::max(1u, p.envBase >> m) + 2u, b = 6u * e * (e - 1u) * 12u;
+                    if (bytes + b > kLdsCubeBytes) break;
+                    bytes += b;
+                    first = m;
+                }
+                for (uint32_t m = 0; m < p.envMips; ++m) {
+                    const uint64_t e = (uint64_t)std::max(1u, p.envBase >> m) + 2u;
+                    bordered += 6u * e * e * 8u;
+                    if (m < first) before += 6u * e * (e - 1u) * 12u;
+                }
+                h.cubeLdsLevel = first < p.envMips ? (float)first : 16.0f;
+                h.cubeLdsBase = (uint32_t)(bordered + before);
+                h.cubeLdsBytes = first < p.envMips ? (uint32_t)bytes : 0u;
             }
             streamed = true;
             const LightingParams& q = p;
