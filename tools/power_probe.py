@@ -44,6 +44,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--balance", type=int, default=1)
+    ap.add_argument("--kernel", choices=["lighting", "stream"], default="lighting", help="stream: the plain four-reads-one-write streaming kernel of the same byte count (ur_debug_stream_ceiling)")
     a = ap.parse_args()
     import torch
     from unclerenderer_amd import assets, hostmath, synth
@@ -60,6 +61,12 @@ def main():
     lut = assets.load_brdf_lut_dds(ad / "PreintegratedGF.dds")
     tables = hp.make_tables(to_device(shadow), hp.stage_env_cube(env, 256, 9), 256, 9, to_device(lut))
     bufs = [dict(A=to_device(g.A), B=to_device(g.B), C=to_device(g.C), D=to_device(g.depth), hdr=to_device(g.hdr)) for _ in range(4)]
+    n16 = 345_000_000 // 80
+    stream_sets = None
+    if a.kernel == "stream":
+        gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+        stream_sets = [([(torch.randint(0, 0x3FFF, (n16 * 8,), dtype=torch.int16, device="cuda", generator=gen) | 0x3000) for _ in range(4)],
+                        torch.empty(n16 * 8, dtype=torch.int16, device="cuda")) for _ in range(3)]
     stop = threading.Event()
     samples = []
 
@@ -74,6 +81,9 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for k in range(2000):
+            if stream_sets is not None:
+                hp.stream_ceiling(*stream_sets[k % 3])
+                continue
             b = bufs[k % 4]
             hp.deferred_lighting_sky(fc.scene, fc.sky, b["A"], b["B"], b["C"], b["D"], tables, b["hdr"], W, H)
         e1.record()
@@ -81,7 +91,9 @@ def main():
         print(f"t={time.perf_counter() - t0:5.2f}s  {e0.elapsed_time(e1) * 1e3 / 2000:.2f} us per launch", flush=True)
     stop.set()
     th.join()
-    keys = sorted({k for _, s in samples for k in s})
+    # only the card that is busy with this process (the box's other cards show in sysfs too)
+    busy = {k.split(":")[0] for _, s in samples for k, v in s.items() if k.endswith("gpu_busy_percent") and v.isdigit() and int(v) > 50}
+    keys = sorted({k for _, s in samples for k in s if k.split(":")[0] in busy})
     for k in keys:
         vals = [s.get(k) for _, s in samples]
         print(k, "->", vals[:: max(1, len(vals) // 12)])
