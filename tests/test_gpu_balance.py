@@ -119,3 +119,45 @@ def test_options_are_validated_and_per_context(urlib):
     finally:
         a.close()
         b.close()
+
+
+def test_balanced_launch_replays_from_a_hip_graph(urlib):
+    """A captured launch with run-time tile claims is replayed as often as the host likes: the claim words are put back to zero by
+    the launch itself (the workgroup whose last claim comes last), not by the host, so a replay finds them as the capture did."""
+    import torch
+    from tests.test_gpu_parity import _device_tables
+    from unclerenderer_amd import lib
+    from unclerenderer_amd.hotpath import HotPath, to_device
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = 1920, 1080
+    fc, g, shadow, env, lut = _inputs(w, h, 73)
+    stream = torch.cuda.Stream()
+    hp = HotPath(0, stream)
+    try:
+        with torch.cuda.stream(stream):
+            tables = _device_tables(hp, shadow, env, lut)
+            dA, dB, dC, dD = to_device(g.A), to_device(g.B), to_device(g.C), to_device(g.depth)
+            hdr0, hdr = to_device(g.hdr), to_device(g.hdr)
+            hp.set_option(lib.UR_OPT_LIGHTING_BALANCE, 0)
+            hp.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, hdr, w, h)
+            stream.synchronize()
+            ref = hdr.clone()
+            hp.set_option(lib.UR_OPT_LIGHTING_BALANCE, 1)
+            hp.set_option(lib.UR_OPT_BALANCE_CHUNK_SHIFT, 2)
+            hdr.copy_(hdr0)
+            hp.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, hdr, w, h)  # (function attributes are set before the capture)
+            stream.synchronize()
+            assert hp.lighting_schedule()["pool_chunks"] > 0 and torch.equal(hdr, ref)
+            graph = torch.cuda.CUDAGraph()
+            hdr.copy_(hdr0)
+            with torch.cuda.graph(graph, stream=stream):
+                hp.deferred_lighting_sky(fc.scene, fc.sky, dA, dB, dC, dD, tables, hdr, w, h)
+            for k in range(4):
+                hdr.copy_(hdr0)
+                graph.replay()
+                stream.synchronize()
+                assert torch.equal(hdr, ref), k
+            hp.flush()
+    finally:
+        hp.close()
