@@ -43,19 +43,30 @@ def main():
     lay = HzbLayout(W, H)
     hzb = torch.zeros(lay.total, device="cuda")
 
-    def run(fn, n=a.iters, warm=1200):
+    def run(fn, n=a.iters, warm=1200, lighting=True):
+        """(loop us per iteration between one event pair - host-bound for launches this short: a ctypes call is ~5 us -, mean duration
+        of the Lighting DISPATCH from events carried on every 8th one: the GPU's own figure, what rocprofv3 would report)"""
         for k in range(warm):
             fn(k)
+        pairs = []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for k in range(n):
+            if lighting and k % 8 == 0:
+                x, y = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                x.record(); y.record()
+                pairs.append((x, y))
+                hp.time_next_lighting(x, y)
             fn(k)
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / n
+        loop = e0.elapsed_time(e1) * 1e3 / n
+        disp = float(np.mean([x.elapsed_time(y) for x, y in pairs])) * 1e3 if pairs else loop
+        return loop, disp
 
     print(f"{W}x{H}; per rank and frame, us (back-to-back, cold buffer sets); N = {H} / band rows")
-    print(f"{'band':>5s} {'N':>3s} {'lighting':>9s} {'replicated rides':>17s} {'sharded rides':>14s} {'+ tail launch':>13s} {'HDR band B':>11s} {'HZB slices B':>13s}")
+    print("dispatch = the Lighting launch's own duration (events carried on the dispatch); loop = back-to-back iterations, host-bound below ~15 us")
+    print(f"{'band':>5s} {'N':>3s} | {'lighting':>9s} {'replicated':>11s} {'sharded':>8s}  (dispatch us) | {'lighting':>9s} {'replicated':>11s} {'sharded':>8s} (loop us) | {'tail launch':>11s} {'HDR band B':>11s} {'HZB slices B':>13s}")
     for band in a.bands:
         world = H // band
         rank = world // 2
@@ -80,9 +91,9 @@ def main():
         t_rep = run(replicated)
         t_shard = run(sharded)
         hp.defer_hzb_tail(0)
-        t_tail = run(lambda k: hp.build_hzb_tail(hzb, lay), n=300, warm=300)
+        t_tail = run(lambda k: hp.build_hzb_tail(hzb, lay), n=300, warm=300, lighting=False)[0]
         slice_bytes = 4 * sum(c for _, c in lay.band_slices(p0, pn))
-        print(f"{band:5d} {world:3d} {t_light:9.1f} {t_rep:17.1f} {t_shard:14.1f} {t_tail:13.1f} {band * W * 8:11d} {slice_bytes if world > 1 else 0:13d}", flush=True)
+        print(f"{band:5d} {world:3d} | {t_light[1]:9.1f} {t_rep[1]:11.1f} {t_shard[1]:8.1f}               | {t_light[0]:9.1f} {t_rep[0]:11.1f} {t_shard[0]:8.1f}           | {t_tail:11.1f} {band * W * 8:11d} {slice_bytes if world > 1 else 0:13d}", flush=True)
     hp.flush()
 
 
