@@ -35,7 +35,10 @@ extern "C" {
 #define UR_ENODEVICE (-4)    /* no usable gfx950 device */
 #define UR_EUNSUPPORTED (-5) /* valid request outside what the kernels implement */
 #define UR_ETIMEOUT (-6)     /* a riding Build HZB chain's tail gave up waiting for its producers inside a Lighting launch: the HZB's
-                                levels from the tail's first one on are stale (ur_flush / ur_build_hzb / ur_cull_indirect_args* report it) */
+                                levels from the tail's first one on are stale - or a wave of a balanced Lighting launch gave up waiting for a
+                                tile claim of its workgroup: tiles of that launch were not shaded. Reported once by the next ur_flush /
+                                ur_build_hzb* / ur_cull_indirect_args* / ur_deferred_lighting* / ur_frame_render on the context, which does
+                                nothing else in that call */
 
 #define UR_MAX_HZB_MIPS 16u
 #define UR_CULL_CONSTANT_DWORDS 46u

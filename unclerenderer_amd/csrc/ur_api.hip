@@ -505,6 +505,8 @@ int ur_deferred_lighting(ur_ctx* ctx, const ur_scene_constants* scene, const ur_
     const int rc = check_band("ur_deferred_lighting", ctx, w, h, row0, rows);
     if (rc != UR_OK) return rc;
     if (!scene || !a || !b || !c || !tables || !hdr) { set_error("ur_deferred_lighting: null argument"); return UR_EINVAL; }
+    const int trc = ur::check_hzb_timeout(ctx, "ur_deferred_lighting"); // (a launch behind one that gave up must not start from its leftovers)
+    if (trc != UR_OK) return trc;
     return ur::launch_lighting(ctx, scene, nullptr, a, b, c, nullptr, tables, hdr, w, h, row0, rows, ur::UR_MODE_LIGHTING);
 }
 
@@ -524,6 +526,8 @@ int ur_deferred_lighting_sky(ur_ctx* ctx, const ur_scene_constants* scene, const
     const int rc = check_band("ur_deferred_lighting_sky", ctx, w, h, row0, rows);
     if (rc != UR_OK) return rc;
     if (!scene || !sky || !a || !b || !c || !depth || !tables || !hdr) { set_error("ur_deferred_lighting_sky: null argument"); return UR_EINVAL; }
+    const int trc = ur::check_hzb_timeout(ctx, "ur_deferred_lighting_sky");
+    if (trc != UR_OK) return trc;
     return ur::launch_lighting(ctx, scene, sky, a, b, c, depth, tables, hdr, w, h, row0, rows, ur::UR_MODE_FUSED);
 }
 
