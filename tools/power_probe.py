@@ -44,6 +44,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--balance", type=int, default=1)
+    ap.add_argument("--no-shadows", action="store_true", help="ShadowStrength = 0: the SHADOWS = false instantiation (no shadow gathers, no PCF)")
+    ap.add_argument("--gbuffer", choices=["scene", "iid"], default="scene")
     ap.add_argument("--kernel", choices=["lighting", "stream"], default="lighting", help="stream: the plain four-reads-one-write streaming kernel of the same byte count (ur_debug_stream_ceiling)")
     a = ap.parse_args()
     import torch
@@ -54,8 +56,14 @@ def main():
     hp.set_option(8, a.balance)
     W, H = 3840, 2160
     fc = hostmath.build_frame_constants("sponza", W, H)
-    g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, W, H, synth.SEED_BASE + 3)
-    shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+    if a.no_shadows:
+        fc.scene.ShadowStrength = 0.0
+    if a.gbuffer == "scene":
+        g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, W, H, synth.SEED_BASE + 3)
+        shadow = synth.shadow_map_scene(np.ctypeslib.as_array(fc.scene.LightViewProjection), 2048)
+    else:
+        g = synth.gbuffer_iid(W, H, synth.SEED_BASE + 3)
+        shadow = synth.shadow_map_noise(2048, synth.SEED_BASE + 3)
     ad = ROOT / "tests" / "golden" / "assets"
     env = assets.load_env_cube_dds(ad / "output_pmrem.dds")[0]
     lut = assets.load_brdf_lut_dds(ad / "PreintegratedGF.dds")
@@ -97,6 +105,10 @@ def main():
     for k in keys:
         vals = [s.get(k) for _, s in samples]
         print(k, "->", vals[:: max(1, len(vals) // 12)])
+        if k.endswith(("power1_input", "freq1_input")):
+            nums = [float(v) for v in vals[len(vals) // 3:] if v and v.isdigit()]  # the steady part
+            if nums:
+                print(f"   steady mean {np.mean(nums) / 1e6:.0f} {'W' if 'power' in k else 'MHz'}")
     try:
         r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp"], capture_output=True, text=True, timeout=20)
         print(r.stdout[-1500:])
