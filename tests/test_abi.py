@@ -34,6 +34,8 @@ def test_struct_layouts(urlib):
     assert lib.SceneConstants.ShadowStrength.offset == 400
     assert lib.SceneConstants.EnvMapMipCount.offset == 576
     assert C.sizeof(lib.MipDesc) == 12
+    assert C.sizeof(lib.LightingTables) == 48 and lib.LightingTables.env_cube_texels.offset == 40  # ur_lighting_tables (the layout tag is its last field)
+    assert C.sizeof(lib.HzbSlice) == 8
     assert lib.UR_INDIRECT_COMMAND_STRIDE == 64 and lib.UR_INDIRECT_INSTANCE_COUNT_OFFSET == 44
 
 
@@ -97,3 +99,17 @@ def test_product_never_reaches_for_the_oracle():
     if lib.exists():
         needed = subprocess.run(["readelf", "-d", str(lib)], capture_output=True, text=True).stdout
         assert "oracle" not in needed
+
+
+def test_hzb_band_helpers_without_a_gpu(urlib):
+    """ur_hzb_band_pieces / ur_hzb_band_slices are host-only: the piece rows of the ranks tile the wide launch, their slices tile mips 0-4."""
+    from unclerenderer_amd.hotpath import HzbLayout
+    for (w, h, n) in [(3840, 2160, 8), (1920, 1080, 3), (1904, 1052, 2), (7680, 4320, 8)]:
+        lay = HzbLayout(w, h)
+        pieces = [lay.band_pieces(n, r) for r in range(n)]
+        assert pieces[0][0] == 0 and pieces[-1][0] + pieces[-1][1] == (h + 31) // 32
+        assert all(a[0] + a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        total = sum(c for p in pieces for _, c in lay.band_slices(*p))
+        assert total == sum(lay.mips[k].width * lay.mips[k].height for k in range(5))
+    a, b = C.c_uint32(0), C.c_uint32(0)
+    assert urlib.ur_hzb_band_pieces(2160, 7, 0, C.byref(a), C.byref(b)) != 0  # 7 does not divide 2160
