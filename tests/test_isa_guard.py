@@ -83,7 +83,7 @@ def test_streaming_kernels_have_no_scratch_and_no_spills(lighting_co):
     assert hot["vgpr_count"] <= 128, hot  # 4 waves per SIMD need <= 128
     for name, m in meta.items():
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
-        if "Li16ELb" in name:  # the shipped configuration (UR_LIGHTING_WPB=12 is a diagnostic one)
+        if "Li16ELb" in name:  # the shipped configuration (UR_OPT_LIGHTING_WAVES_PER_WG = 12 is a diagnostic one)
             assert m["sgpr_spill_count"] <= 8 and m["vgpr_count"] <= 128, (name, m)  # (what the loop sees of them: test_no_spill_traffic_inside_the_loop)
 
 

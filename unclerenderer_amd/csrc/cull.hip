@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
         const uint32_t value = visible ? 1u : 0u;
         // Write-through (sc1): each word is alone in its 64-byte command, so a store is one fabric write whenever it leaves L2; leaving at
         // once means the launch ends with nothing dirty to write back (1 M instances: 22.6 -> 20.0 us words only, 29.1 -> 26.7 with
-        // the list; nontemporal stores changed nothing). UR_CULL_STORE=0 / 1 select plain / nontemporal stores for comparison.
+        // the list; nontemporal stores changed nothing). UR_OPT_CULL_STORE = 0 / 1 select plain / nontemporal stores for comparison.
         if (C.store_flavour == 2u) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(word), "v"(value) : "memory");
         else if (C.store_flavour == 1u) __builtin_nontemporal_store(value, word);
         else *word = value;

@@ -989,7 +989,7 @@ __global__ __launch_bounds__(64 * WPB, 1) void lighting_stream_kernel(LightingPa
     }
     // ---- the tables: converted and written to LDS once per workgroup ------------------------------------------------------
     {
-        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; work[3] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces
+        if (threadIdx.x == 0) { work[0] = 2u * WPB; work[1] = 0u; work[2] = 0u; work[3] = 0u; } // [0] next tile claim, [1] waves that have left the loop (debug timeline), [2] waves done with their HZB pieces, [3] waves whose pieces of the cube's small mips have landed in LDS
         if (p.bal.poolChunks != 0u && threadIdx.x < kDynSlots) { // uniform: the run-time part of the tile schedule (struct Balance)
             // this workgroup's claim word q serves workgroups [8q, 8q + 8): its share of the pool is chunks [P0, P1); the first
             // `lookahead` chunks of each of its nq workgroups are pre-assigned, the rest is claimed
