@@ -563,18 +563,21 @@ def stream_ceiling_leg(hp, torch, nbytes, dev):
     return {"bytes_per_launch": moved, "dispatch_us": disp_us, "loop_us": loop_us, "GBps": moved / disp_us / 1e3, "loop_GBps": moved / loop_us / 1e3}
 
 
-def _time_events(torch, fn, iters, warm=5):
+def _time_events(torch, fn, iters, warm=5, batch=16):
+    """Per-call time of fn: `batch` calls back to back between ONE event pair, `iters` such pairs (an event record costs ~5 us of queue
+    time on this stack: around a single call it would be a fifth of what a 25-us kernel reads). Returns (median, min) seconds per call."""
     for _ in range(warm):
         fn()
     evs = []
     for _ in range(iters):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(batch):
+            fn()
         b.record()
         evs.append((a, b))
     torch.cuda.synchronize()
-    t = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3
+    t = np.array([a.elapsed_time(b) for a, b in evs]) * 1e-3 / batch
     return float(np.median(t)), float(t.min())
 
 
@@ -621,9 +624,24 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
     g8 = synth.gbuffer_scene(fc8.view, fc8.proj, fc8.camera_position, W8, H8, synth.SEED_BASE + 5)
     depth8 = to_device(g8.depth, dev)
     hzb8 = torch.zeros(lay8.total, dtype=torch.float32, device=f"cuda:{dev}")
-    med, mn = _time_events(torch, lambda: hp.build_hzb(depth8, hzb8, lay8), 30)
+    # cold inputs, as in the lighting legs: three depth buffers and chains (3 x 177 MB) so that no launch finds its source in the
+    # 256-MB memory-side cache the launch before left there; the same buffers over and over ("warm") is reported beside it
+    kring = 3
+    depths = [depth8] + [depth8.clone() for _ in range(kring - 1)]
+    hzbs = [hzb8] + [torch.zeros_like(hzb8) for _ in range(kring - 1)]
+    turn = [0]
+
+    def hzb_cold():
+        k = turn[0] % kring
+        turn[0] += 1
+        hp.build_hzb(depths[k], hzbs[k], lay8)
+
+    med, mn = _time_events(torch, hzb_cold, 12, batch=15)
+    med_w, _ = _time_events(torch, lambda: hp.build_hzb(depth8, hzb8, lay8), 12)
     hzb_bytes = 4 * (W8 * H8 + lay8.mip_texels())
-    out["build_hzb_8k"] = {"median_us": med * 1e6, "GBps": hzb_bytes / med / 1e9, "frac_hbm": hzb_bytes / med / 1e9 / HBM_PEAK_GBS}
+    out["build_hzb_8k"] = {"median_us": med * 1e6, "GBps": hzb_bytes / med / 1e9, "frac_hbm": hzb_bytes / med / 1e9 / HBM_PEAK_GBS,
+                           "inputs": "three buffer sets cycled (cold)", "same_buffers_us": med_w * 1e6}
+    del depths[1:], hzbs[1:]
     bounds = to_device(synth.instances_random(n, synth.SEED_BASE + 5, center=fc8.camera_position, box=400.0), dev)
     d_args = to_device(synth.indirect_args_initial(n), dev)
     d_vis = torch.zeros(n, dtype=torch.int32, device=f"cuda:{dev}")
@@ -635,7 +653,17 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
     frustum_culled, occluded = (int(v) for v in d_stats.cpu().numpy().view(np.uint32))
     visible = int(d_cnt.cpu().numpy().view(np.uint32)[0])
     consts = hostmath.pack_culling_constants(fc8.view, fc8.proj, n, True, lay8.count, lay8.width, lay8.height, False)
-    med, mn = _time_events(torch, lambda: hp.cull_indirect_args(consts, bounds, hzb8, lay8, d_args, None, d_vis, d_cnt), 50)
+    cring = 4  # 4 x (32 MB of bounds + 64 MB of commands + the list): cold, as above
+    csets = [(bounds, d_args, d_vis)] + [(bounds.clone(), d_args.clone(), torch.zeros_like(d_vis)) for _ in range(cring - 1)]
+
+    def cull_cold():
+        b_, a_, v_ = csets[turn[0] % cring]
+        turn[0] += 1
+        hp.cull_indirect_args(consts, b_, hzb8, lay8, a_, None, v_, d_cnt)
+
+    med, mn = _time_events(torch, cull_cold, 12)
+    med_w, _ = _time_events(torch, lambda: hp.cull_indirect_args(consts, bounds, hzb8, lay8, d_args, None, d_vis, d_cnt), 12)
+    del csets[1:]
     f_frustum = 1.0 - frustum_culled / n
     cull_bytes = n * (36 + 16 * f_frustum) + 4 * visible
     # SURVEY.md section 8d asks for both accountings: the algorithmic 4 B per InstanceCount word, and the 64-byte line each of those
@@ -644,7 +672,8 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
     out["cull_1m"] = {"instances": n, "visible": visible, "frustum_culled": frustum_culled, "occluded": occluded,
                       "median_us": med * 1e6, "instances_per_s": n / med, "algorithmic_GBps": cull_bytes / med / 1e9,
                       "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS,
-                      "with_64B_store_lines_GBps": line_bytes / med / 1e9, "frac_hbm_with_64B_store_lines": line_bytes / med / 1e9 / HBM_PEAK_GBS}
+                      "with_64B_store_lines_GBps": line_bytes / med / 1e9, "frac_hbm_with_64B_store_lines": line_bytes / med / 1e9 / HBM_PEAK_GBS,
+                      "inputs": "four buffer sets cycled (cold)", "same_buffers_us": med_w * 1e6}
     # ---- fused Lighting+Sky on the other G-buffers the contract names: the independent-per-pixel generator
     #      at the frame size (the stress case: every lane gathers its own cube / LUT / shadow line), C2's 1920x1080 and C5's
     #      7680x4320, Sponza constants, shipped IBL tables. Back-to-back launches over cold buffer sets between ONE event pair.
