@@ -653,7 +653,7 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
     frustum_culled, occluded = (int(v) for v in d_stats.cpu().numpy().view(np.uint32))
     visible = int(d_cnt.cpu().numpy().view(np.uint32)[0])
     consts = hostmath.pack_culling_constants(fc8.view, fc8.proj, n, True, lay8.count, lay8.width, lay8.height, False)
-    cring = 4  # 4 x (32 MB of bounds + 64 MB of commands + the list): cold, as above
+    cring = 6  # 6 x (32 MB of bounds + 64 MB of commands + the list): cold, as above
     csets = [(bounds, d_args, d_vis)] + [(bounds.clone(), d_args.clone(), torch.zeros_like(d_vis)) for _ in range(cring - 1)]
 
     def cull_cold():
@@ -663,7 +663,26 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
 
     med, mn = _time_events(torch, cull_cold, 12)
     med_w, _ = _time_events(torch, lambda: hp.cull_indirect_args(consts, bounds, hzb8, lay8, d_args, None, d_vis, d_cnt), 12)
-    del csets[1:]
+    # The launch leaves a word that already holds its value alone (UR_OPT_CULL_STORE = 3), and the legs above find the command buffer as
+    # the previous launch left it - the steady frame. The other end: every command back to InstanceCount = 1 ahead of its launch (a first
+    # frame, a camera cut: 99 % of these words then change). The reset of a set runs three launches ahead of its use so that the copy
+    # has left the caches again; per-launch event pairs (the copies lie outside them; ~3 us of event cost inside).
+    args_initial = d_args.clone()
+    args_initial.copy_(to_device(synth.indirect_args_initial(n), dev))
+    evs = []
+    for k in range(cring):
+        csets[k][1].copy_(args_initial)
+    for i in range(40):
+        b_, a_, v_ = csets[i % cring]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hp.cull_indirect_args(consts, b_, hzb8, lay8, a_, None, v_, d_cnt)
+        e1.record()
+        evs.append((e0, e1))
+        csets[(i + 3) % cring][1].copy_(args_initial)  # used three launches from now
+    torch.cuda.synchronize()
+    med_reset = float(np.median([x.elapsed_time(y) for x, y in evs[8:]])) * 1e-3
+    del csets[1:], args_initial
     f_frustum = 1.0 - frustum_culled / n
     cull_bytes = n * (36 + 16 * f_frustum) + 4 * visible
     # SURVEY.md section 8d asks for both accountings: the algorithmic 4 B per InstanceCount word, and the 64-byte line each of those
@@ -673,7 +692,8 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
                       "median_us": med * 1e6, "instances_per_s": n / med, "algorithmic_GBps": cull_bytes / med / 1e9,
                       "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS,
                       "with_64B_store_lines_GBps": line_bytes / med / 1e9, "frac_hbm_with_64B_store_lines": line_bytes / med / 1e9 / HBM_PEAK_GBS,
-                      "inputs": "four buffer sets cycled (cold)", "same_buffers_us": med_w * 1e6}
+                      "inputs": "six buffer sets cycled (cold); command buffers as the previous frame left them (no word changes)",
+                      "same_buffers_us": med_w * 1e6, "every_word_reset_first_us": med_reset * 1e6}
     # ---- fused Lighting+Sky on the other G-buffers the contract names: the independent-per-pixel generator
     #      at the frame size (the stress case: every lane gathers its own cube / LUT / shadow line), C2's 1920x1080 and C5's
     #      7680x4320, Sponza constants, shipped IBL tables. Back-to-back launches over cold buffer sets between ONE event pair.

@@ -102,6 +102,48 @@ def _cull_case(hotpath, oracle, n, hzb_on, seed, w=480, h=270, debug=True, index
     return ref_cnt, ref_stats
 
 
+@pytest.mark.parametrize("n", [25, 257, 20_000])
+def test_cull_store_flavours_leave_the_same_bytes(hotpath, oracle, n):
+    """UR_OPT_CULL_STORE 0..3 (plain, nontemporal, write-through, write-through of changed words only - the default): whatever the
+    InstanceCount words hold when the launch starts (the reference's 1, last frame's result, zeros, garbage), the command buffer ends
+    up byte-equal to the oracle's, dword 11 and everything around it."""
+    from unclerenderer_amd import hostmath, lib, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    torch = _torch()
+    w, h = 480, 270
+    fc = hostmath.build_frame_constants("sponza", w, h)
+    g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 11)
+    lay = HzbLayout(w, h)
+    hzb_ref = np.nan_to_num(oracle.build_hzb(g.depth, lay.as_list(), lay.total), nan=0.0)
+    bounds = synth.instances_random(n, 11 + n, center=fc.camera_position, box=120.0)
+    consts = hostmath.pack_culling_constants(fc.view, fc.proj, n, True, lay.count, lay.width, lay.height, False)
+    args0 = synth.indirect_args_initial(n)
+    ref_args, _, ref_vis, ref_cnt = oracle.cull_indirect_args(consts, bounds, hzb_ref, lay.as_list(), args0, 0)
+    assert hotpath.get_option(lib.UR_OPT_CULL_STORE) == 3
+    d_bounds, d_hzb = to_device(bounds), to_device(hzb_ref)
+    rng = np.random.default_rng(5)
+    starts = {"ones": args0, "result": ref_args}
+    for name, fill in (("zeros", 0), ("garbage", None)):
+        a = args0.copy()
+        a[:, 11] = fill if fill is not None else rng.integers(2, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        starts[name] = a
+    try:
+        for flavour in (0, 1, 2, 3):
+            hotpath.set_option(lib.UR_OPT_CULL_STORE, flavour)
+            for name, start in starts.items():
+                d_args = to_device(np.ascontiguousarray(start))
+                d_vis = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+                d_cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+                hotpath.cull_indirect_args(consts, d_bounds, d_hzb, lay, d_args, None, d_vis, d_cnt, 0)
+                torch.cuda.synchronize()
+                got = d_args.cpu().numpy().view(np.uint32).reshape(n, 16)
+                assert np.array_equal(got, ref_args), f"flavour {flavour}, start {name}"
+                assert int(d_cnt.cpu().numpy().view(np.uint32)[0]) == ref_cnt
+                assert np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt], ref_vis)
+    finally:
+        hotpath.set_option(lib.UR_OPT_CULL_STORE, 3)
+
+
 @pytest.mark.parametrize("n", [1, 25, 63, 64, 65, 170, 256, 257, 1023, 4097, 100_000])
 @pytest.mark.parametrize("hzb_on", [False, True])
 def test_cull_bit_exact(hotpath, oracle, n, hzb_on):

@@ -133,15 +133,21 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
     const uint32_t index = first + tid;
     ur::timeline_entry(C.timeline);
 
-    // stage this block's AABBs: 512 float4, lane-consecutive 16-byte loads
-    const uint32_t nb = min(512u, (C.ModelCount - first) * 2u);
+    // stage this block's AABBs: 512 float4, lane-consecutive 16-byte loads. Every load of the thread goes out before the first LDS
+    // write (clamped indices instead of branches: one memory latency, not two or three in a row)
+    const uint32_t nb = min(512u, (C.ModelCount - first) * 2u); // >= 2: the block has an instance
     const float4* src = C.bounds + (size_t)first * 2u;
-    if (tid < nb) sb[tid] = src[tid];
-    if (tid + 256u < nb) sb[tid + 256u] = src[tid + 256u];
-    __syncthreads();
+    const float4 s0 = src[min(tid, nb - 1u)], s1 = src[min(tid + 256u, nb - 1u)];
 
     bool visible = false, frustumVisible = true, occluded = false;
     const bool active = index < C.ModelCount;
+    // UR_OPT_CULL_STORE = 3: the word's present value, fetched with the AABBs (its latency lies under the barrier and the tests)
+    uint32_t old_word = 0xFFFFFFFFu;
+    if (C.store_flavour == 3u) // (launch-uniform)
+        old_word = *reinterpret_cast<const uint32_t*>(C.args + (size_t)min(index, C.ModelCount - 1u) * UR_INDIRECT_COMMAND_STRIDE + UR_INDIRECT_INSTANCE_COUNT_OFFSET);
+    if (tid < nb) sb[tid] = s0;
+    if (tid + 256u < nb) sb[tid + 256u] = s1;
+    __syncthreads();
     if (active) {
         const float4 bmin = sb[2u * tid], bmax = sb[2u * tid + 1u];
         const float3 mn = make_float3(bmin.x, bmin.y, bmin.z), mx = make_float3(bmax.x, bmax.y, bmax.z);
@@ -156,7 +162,14 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
         // Write-through (sc1): each word is alone in its 64-byte command, so a store is one fabric write whenever it leaves L2; leaving at
         // once means the launch ends with nothing dirty to write back (1 M instances: 22.6 -> 20.0 us words only, 29.1 -> 26.7 with
         // the list; nontemporal stores changed nothing). UR_OPT_CULL_STORE = 0 / 1 select plain / nontemporal stores for comparison.
-        if (C.store_flavour == 2u) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(word), "v"(value) : "memory");
+        // UR_OPT_CULL_STORE = 3 (default): a word that already holds its value is left alone. The command buffer lives across frames
+        // (the reference uploads it once per scene, Source/Render/DeferredRenderer.cpp:3397-3442, and its shader rewrites dword 11 in
+        // place every frame), and from one frame to the next few instances change sides: the store - a 4-byte write into a 64-byte
+        // line of its own, i.e. a read-modify-write of that line in memory - then happens for those few only, the rest costs the
+        // 4-byte read. Memory ends up the same in every case (1 M instances over cold buffers: see DESIGN.md 3.2).
+        if (C.store_flavour == 3u) {
+            if (old_word != value) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(word), "v"(value) : "memory");
+        } else if (C.store_flavour == 2u) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(word), "v"(value) : "memory");
         else if (C.store_flavour == 1u) __builtin_nontemporal_store(value, word);
         else *word = value;
     }

@@ -255,7 +255,7 @@ bool option_slot(int option, OptionSlot& o)
     case UR_OPT_LIGHTING_TILED_WAVES: o = {&O::tiled_waves, 4, 6, true}; return true;
     case UR_OPT_LIGHTING_LEAVE_CUS: o = {&O::leave_cus, 0, 128, false}; return true;
     case UR_OPT_RIDE_WALKERS: o = {&O::ride_walkers, 0, 16, false}; return true;
-    case UR_OPT_CULL_STORE: o = {&O::cull_store, 0, 2, false}; return true;
+    case UR_OPT_CULL_STORE: o = {&O::cull_store, 0, 3, false}; return true;
     case UR_OPT_LIGHTING_BALANCE: o = {&O::balance, 0, 1, false}; return true;
     case UR_OPT_BALANCE_POOL_16THS: o = {&O::balance_pool_16ths, 1, 8, false}; return true;
     case UR_OPT_BALANCE_CHUNK_SHIFT: o = {&O::balance_chunk_shift, 2, 6, false}; return true;

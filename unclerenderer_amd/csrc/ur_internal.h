@@ -58,7 +58,7 @@ struct ur_ctx {
     bool time_cull_carried = false;      // ... and whether a dispatch of that call took it (ur_time_cull_carried)
     // ur_set_option: launch-shape choices of this context (include/ur_hotpath.h, UR_OPT_*)
     struct Options {
-        int lighting_stream = 1, lighting_wpb = 16, tiled_waves = 6, leave_cus = 0, ride_walkers = 0, cull_store = 2;
+        int lighting_stream = 1, lighting_wpb = 16, tiled_waves = 6, leave_cus = 0, ride_walkers = 0, cull_store = 3;
         int balance = 1, balance_pool_16ths = 3, balance_chunk_shift = 4;
         int debug_hzb_ride_stall = 0;
     } opt;
