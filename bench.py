@@ -73,6 +73,8 @@ def parse():
                     help="host pacing: the host waits (once every 64 frames) until the GPU is within this many frames of it (the reference "
                          "keeps 3 frames in flight, Core/Application.cpp:567-573). 0 = unpaced (default): the host runs ~8x ahead of the GPU, "
                          "which is what hides its own pauses")
+    ap.add_argument("--no-spin-fence", action="store_true", help="end the timed region with torch.cuda.synchronize() alone instead of spinning on a "
+                                                                 "stream-written word of pinned memory in front of it")
     ap.add_argument("--python-gc", action="store_true",
                     help="leave Python's cyclic garbage collector on during the frames. Off by default: a full collection of this process's "
                          "heap takes the submitting thread 35-55 ms at an allocation count that falls inside the timed region, and whenever "
@@ -290,6 +292,37 @@ def main():
             else:
                 s["gather"] = urdist.allgather_hdr(s["hdr_full"], s["hdr_band"], async_op=not args.sync_gather, mode=args.gather)
 
+    # The host notices the end of the queue by SPINNING on a word of pinned memory that the stream writes behind the last frame
+    # (hipStreamWriteValue32: a queue packet, no kernel), and only then calls torch.cuda.synchronize(), which finds nothing left to
+    # wait for: a blocking synchronize alone adds the runtime's wake-up latency (tens of microseconds) to whatever it brackets, which
+    # is 2-3 % of a 20-frame timed region. (--no-spin-fence: the plain synchronize.)
+    spin = {"hip": None, "flag": None, "np": None, "seq": 0, "used": 0}
+    if not args.no_spin_fence and not args.graph:
+        try:
+            import ctypes
+            spin["hip"] = ctypes.CDLL("libamdhip64.so")
+            spin["hip"].hipStreamWriteValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint]
+            spin["hip"].hipStreamWriteValue32.restype = ctypes.c_int
+            spin["flag"] = torch.zeros(16, dtype=torch.int32).pin_memory()
+            spin["np"] = spin["flag"].numpy()
+        except Exception:
+            spin["hip"] = None
+
+    def spin_until_queue_is_empty():
+        if spin["hip"] is None:
+            return
+        spin["seq"] += 1
+        rc = spin["hip"].hipStreamWriteValue32(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(spin["flag"].data_ptr()),
+                                               ctypes.c_uint32(spin["seq"]), 0)
+        if rc != 0:  # not supported on this stack: the plain synchronize does the waiting
+            spin["hip"] = None
+            return
+        word, want, t_end = spin["np"], spin["seq"], time.perf_counter() + 10.0
+        while word[0] != want:
+            if time.perf_counter() > t_end:
+                break
+        spin["used"] += 1
+
     def fence():
         for s in sets:
             if s.get("gather") is not None:
@@ -297,6 +330,7 @@ def main():
                 s["gather"] = None
         if args.async_compute:
             frame.join_async()
+        spin_until_queue_is_empty()
         torch.cuda.synchronize()
         if N > 1:
             dist.barrier()
@@ -456,6 +490,7 @@ def main():
         "untimed_frames_total": ramp_frames + args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "host_submit_ms_per_step": t_enqueued / args.steps * 1e3,
+        "end_of_region": ("spin on a stream-written pinned word, then torch.cuda.synchronize()" if spin["used"] else "torch.cuda.synchronize()"),
         "host_submit_unthrottled_ms_per_step": host_unthrottled_ms,
         "higher_is_better": True,
         "scaling": "strong",
