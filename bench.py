@@ -717,6 +717,19 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
         csets[(i + 3) % cring][1].copy_(args_initial)  # used three launches from now
     torch.cuda.synchronize()
     med_reset = float(np.median([x.elapsed_time(y) for x, y in evs[8:]])) * 1e-3
+    # UR_OPT_CULL_STORE = 4 (opt-in: the caller promises that only this context's culls write the words): the present values come from
+    # the context's one-bit-per-instance record of its previous launch on the same command buffer instead of from the 64 MB of command
+    # lines. One command buffer (the record is per buffer; it is not read at all), the bounds still cycle cold.
+    from unclerenderer_amd import lib as urlib_
+    hp.set_option(urlib_.UR_OPT_CULL_STORE, 4)
+
+    def cull_record():
+        b_, _, v_ = csets[turn[0] % cring]
+        turn[0] += 1
+        hp.cull_indirect_args(consts, b_, hzb8, lay8, d_args, None, v_, d_cnt)
+
+    med_rec, _ = _time_events(torch, cull_record, 12)
+    hp.set_option(urlib_.UR_OPT_CULL_STORE, 3)
     del csets[1:], args_initial
     f_frustum = 1.0 - frustum_culled / n
     cull_bytes = n * (36 + 16 * f_frustum) + 4 * visible
@@ -728,7 +741,8 @@ def side_measurements(args, hp, fc, torch, to_device, HzbLayout, synth, hostmath
                       "frac_hbm": cull_bytes / med / 1e9 / HBM_PEAK_GBS,
                       "with_64B_store_lines_GBps": line_bytes / med / 1e9, "frac_hbm_with_64B_store_lines": line_bytes / med / 1e9 / HBM_PEAK_GBS,
                       "inputs": "six buffer sets cycled (cold); command buffers as the previous frame left them (no word changes)",
-                      "same_buffers_us": med_w * 1e6, "every_word_reset_first_us": med_reset * 1e6}
+                      "same_buffers_us": med_w * 1e6, "every_word_reset_first_us": med_reset * 1e6,
+                      "from_the_contexts_record_us": med_rec * 1e6, "from_the_contexts_record_instances_per_s": n / med_rec}
     # ---- fused Lighting+Sky on the other G-buffers the contract names: the independent-per-pixel generator
     #      at the frame size (the stress case: every lane gathers its own cube / LUT / shadow line), C2's 1920x1080 and C5's
     #      7680x4320, Sponza constants, shipped IBL tables. Back-to-back launches over cold buffer sets between ONE event pair.

@@ -204,7 +204,13 @@ int ur_time_cull_carried(const ur_ctx* ctx);
 #define UR_OPT_LIGHTING_TILED_WAVES 3   /* [6] register budget of the per-tile kernel, in waves per SIMD: 6 (80 VGPRs) or 4 (uncapped) */
 #define UR_OPT_LIGHTING_LEAVE_CUS 4     /* [0] CUs the persistent lighting workgroups leave to kernels of other streams, 0..128 */
 #define UR_OPT_RIDE_WALKERS 5           /* [0] riding Build HZB chain: 0 = chosen per launch, 1 = one wave per workgroup walks the pieces, 16 = all */
-#define UR_OPT_CULL_STORE 7             /* [3] InstanceCount word stores: 3 = write-through (sc1), only words whose value changes; 2 = write-through, every word; 1 = nontemporal; 0 = plain */
+#define UR_OPT_CULL_STORE 7             /* [3] InstanceCount word stores: 3 = write-through (sc1), only words whose value changes (the kernel reads the present
+                                           value first); 2 = write-through, every word; 1 = nontemporal; 0 = plain; 4 = as 3, but for culls of more than 256
+                                           instances the present values come from the CONTEXT'S RECORD (one bit per instance) of its previous launch on the
+                                           same command buffer with the same count - 1/500 of the bytes. The caller promises that nothing but this context's
+                                           culls writes those words between two launches; setting the option (again) forgets the record, so does a launch on
+                                           another buffer or count, a cull of <= 256 instances, ur_reserve growing the workspace. Same bytes in memory while
+                                           the promise holds */
 #define UR_OPT_LIGHTING_BALANCE 8       /* [1] 1 = the last part of a streaming launch's tiles is claimed by the workgroups at run time
                                            (inter-workgroup balancing), 0 = every tile dealt statically */
 #define UR_OPT_BALANCE_POOL_16THS 9     /* [3] that part, in sixteenths of the launch's tiles, 1..8 */

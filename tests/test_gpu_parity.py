@@ -144,6 +144,66 @@ def test_cull_store_flavours_leave_the_same_bytes(hotpath, oracle, n):
         hotpath.set_option(lib.UR_OPT_CULL_STORE, 3)
 
 
+@pytest.mark.parametrize("with_list", [True, False])
+def test_cull_store_from_the_contexts_record(hotpath, oracle, with_list):
+    """UR_OPT_CULL_STORE = 4: the words' present values are taken from the context's one-bit-per-instance record of its previous launch on
+    the same command buffer. A sequence that changes camera, buffer, count and (with the option set anew, as the contract asks) lets somebody
+    else overwrite the words: after every launch the command buffer is byte-equal to the oracle's."""
+    from unclerenderer_amd import hostmath, lib, synth
+    from unclerenderer_amd.hotpath import HzbLayout, to_device
+    torch = _torch()
+    w, h, n = 480, 270, 5000
+    lay = HzbLayout(w, h)
+    cams = []
+    for k, preset in enumerate(("sponza", "pica_pica")):
+        fc = hostmath.build_frame_constants(preset, w, h)
+        g = synth.gbuffer_scene(fc.view, fc.proj, fc.camera_position, w, h, 21 + k)
+        hzb = np.nan_to_num(oracle.build_hzb(g.depth, lay.as_list(), lay.total), nan=0.0)
+        cams.append((fc, hzb, to_device(hzb)))
+    bounds = synth.instances_random(n, 77, center=cams[0][0].camera_position, box=120.0)
+    d_bounds = to_device(bounds)
+    args0 = synth.indirect_args_initial(n)
+    rng = np.random.default_rng(9)
+    garbage = args0.copy()
+    garbage[:, 11] = rng.integers(0, 3, n).astype(np.uint32)
+    bufs = {"x": to_device(args0), "y": to_device(garbage)}
+    hotpath.set_option(lib.UR_OPT_CULL_STORE, 4)
+    try:
+        def launch(buf, cam, count):
+            fc, hzb_ref, d_hzb = cams[cam]
+            consts = hostmath.pack_culling_constants(fc.view, fc.proj, count, True, lay.count, lay.width, lay.height, False)
+            d_vis = torch.full((n,), -1, dtype=torch.int32, device="cuda") if with_list else None
+            d_cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda") if with_list else None
+            before = bufs[buf].cpu().numpy().view(np.uint32).reshape(n, 16).copy()
+            hotpath.cull_indirect_args(consts, d_bounds, d_hzb, lay, bufs[buf], None, d_vis, d_cnt, 0)
+            torch.cuda.synchronize()
+            ref_args, _, ref_vis, ref_cnt = oracle.cull_indirect_args(consts, bounds[:count], hzb_ref, lay.as_list(), before[:count].copy(), 0)
+            got = bufs[buf].cpu().numpy().view(np.uint32).reshape(n, 16)
+            assert np.array_equal(got[:count], ref_args), f"buffer {buf}, camera {cam}, count {count}"
+            assert np.array_equal(got[count:], before[count:]), "commands behind the count were touched"
+            if with_list:
+                assert int(d_cnt.cpu().numpy().view(np.uint32)[0]) == ref_cnt
+                assert np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt], ref_vis)
+            return ref_args[:, 11].copy()
+
+        a = launch("x", 0, n)      # no record yet: the words are read
+        b = launch("x", 1, n)      # another camera, from the record
+        assert (a != b).any(), "the two cameras must disagree on some instance for the record to matter"
+        launch("x", 0, n)          # and back
+        launch("y", 0, n)          # another buffer, arbitrary words in it: no record for it
+        launch("y", 1, n)
+        launch("x", 1, n)          # back on x: the record is y's, the words are read
+        launch("x", 0, n - 300)    # a shorter count: no record
+        launch("x", 1, n - 300)
+        # somebody else rewrites the words; the caller says so by setting the option anew
+        bufs["x"].copy_(to_device(garbage))
+        hotpath.set_option(lib.UR_OPT_CULL_STORE, 4)
+        launch("x", 1, n - 300)
+        launch("x", 0, n - 300)
+    finally:
+        hotpath.set_option(lib.UR_OPT_CULL_STORE, 3)
+
+
 @pytest.mark.parametrize("n", [1, 25, 63, 64, 65, 170, 256, 257, 1023, 4097, 100_000])
 @pytest.mark.parametrize("hzb_on", [False, True])
 def test_cull_bit_exact(hotpath, oracle, n, hzb_on):

@@ -38,6 +38,7 @@ struct CullParams {
     uint64_t* wave_masks;
     uint32_t index_base;
     uint32_t store_flavour;
+    uint32_t record_valid; // store_flavour 4: wave_masks holds the visible bits this context's previous launch left in THIS command buffer
     uint32_t mip_offset[UR_MAX_HZB_MIPS];
     uint32_t mip_width[UR_MAX_HZB_MIPS];
     unsigned long long* timeline; // debug: {first entry, last exit} of this launch (ur_debug_timeline), else null
@@ -127,6 +128,8 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
 {
     __shared__ float4 sb[512];
     __shared__ uint64_t smask[4];
+    __shared__ uint32_t scand[4];
+    __shared__ uint8_t slist[256], socc[256];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t first = blockIdx.x * 256u;
@@ -142,21 +145,45 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
     bool visible = false, frustumVisible = true, occluded = false;
     const bool active = index < C.ModelCount;
     // UR_OPT_CULL_STORE = 3: the word's present value, fetched with the AABBs (its latency lies under the barrier and the tests)
+    // UR_OPT_CULL_STORE = 4: ... taken from the context's record instead - one bit per instance, the wave masks of its previous launch on
+    // this command buffer (125 KB for 1 M instances instead of 64 MB of command lines); without a valid record, as 3
     uint32_t old_word = 0xFFFFFFFFu;
-    if (C.store_flavour == 3u) // (launch-uniform)
+    const bool from_record = !SINGLE_BLOCK && C.store_flavour == 4u && C.record_valid != 0u; // (launch-uniform)
+    uint64_t old_mask = 0;
+    if (from_record) old_mask = C.wave_masks[(size_t)blockIdx.x * 4u + wave];
+    else if (C.store_flavour >= 3u)
         old_word = *reinterpret_cast<const uint32_t*>(C.args + (size_t)min(index, C.ModelCount - 1u) * UR_INDIRECT_COMMAND_STRIDE + UR_INDIRECT_INSTANCE_COUNT_OFFSET);
     if (tid < nb) sb[tid] = s0;
     if (tid + 256u < nb) sb[tid + 256u] = s1;
     __syncthreads();
     if (active) {
         const float4 bmin = sb[2u * tid], bmax = sb[2u * tid + 1u];
-        const float3 mn = make_float3(bmin.x, bmin.y, bmin.z), mx = make_float3(bmax.x, bmax.y, bmax.z);
-        frustumVisible = IsAabbVisible(C, mn, mx);
-        visible = frustumVisible;
-        if (visible && C.HZBEnabled != 0) {
-            occluded = IsOccluded(C, mn, mx);
-            visible = !occluded;
+        frustumVisible = IsAabbVisible(C, make_float3(bmin.x, bmin.y, bmin.z), make_float3(bmax.x, bmax.y, bmax.z));
+    }
+    if (C.HZBEnabled != 0) { // (launch-uniform)
+        // The occlusion test (eight corners projected with IEEE divides, a mip choice, four taps) is several times the frustum test, and
+        // only what the frustum lets through takes it - one instance in nine of the 1 M stress set: run lane by lane, every wave paid for
+        // it at a ninth of its lanes. The block's survivors are packed first (ballots + popcounts, their indices in LDS) and tested
+        // densely by the block's first wave(s); every instance still runs the same statements on its own bounds.
+        const bool cand = active && frustumVisible;
+        const uint64_t cm = __ballot(cand);
+        if (lane == 0) scand[wave] = (uint32_t)__popcll(cm);
+        __syncthreads();
+        uint32_t at = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) { at += w < wave ? scand[w] : 0u; total += scand[w]; }
+        if (cand) slist[at + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+        __syncthreads();
+        if (tid < total) {
+            const uint32_t j = slist[tid];
+            const float4 bmin = sb[2u * j], bmax = sb[2u * j + 1u];
+            socc[j] = IsOccluded(C, make_float3(bmin.x, bmin.y, bmin.z), make_float3(bmax.x, bmax.y, bmax.z)) ? 1u : 0u;
         }
+        __syncthreads();
+        occluded = cand && socc[tid] != 0u;
+    }
+    if (active) {
+        visible = frustumVisible && !occluded;
         uint32_t* word = reinterpret_cast<uint32_t*>(C.args + (size_t)index * UR_INDIRECT_COMMAND_STRIDE + UR_INDIRECT_INSTANCE_COUNT_OFFSET);
         const uint32_t value = visible ? 1u : 0u;
         // Write-through (sc1): each word is alone in its 64-byte command, so a store is one fabric write whenever it leaves L2; leaving at
@@ -167,7 +194,8 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
         // place every frame), and from one frame to the next few instances change sides: the store - a 4-byte write into a 64-byte
         // line of its own, i.e. a read-modify-write of that line in memory - then happens for those few only, the rest costs the
         // 4-byte read. Memory ends up the same in every case (1 M instances over cold buffers: see DESIGN.md 3.2).
-        if (C.store_flavour == 3u) {
+        if (C.store_flavour >= 3u) {
+            if (from_record) old_word = (uint32_t)(old_mask >> lane) & 1u;
             if (old_word != value) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(word), "v"(value) : "memory");
         } else if (C.store_flavour == 2u) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(word), "v"(value) : "memory");
         else if (C.store_flavour == 1u) __builtin_nontemporal_store(value, word);
@@ -184,6 +212,10 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
     }
 
     if (C.visible_idx == nullptr) { // uniform
+        if (!SINGLE_BLOCK && C.store_flavour == 4u) { // the record of what the command buffer holds now (a launch with a list writes it below)
+            const uint64_t m = __ballot(visible);
+            if (lane == 0) C.wave_masks[(size_t)blockIdx.x * 4u + wave] = m;
+        }
         ur::timeline_exit(C.timeline, tid == 0);
         return;
     }
@@ -283,6 +315,7 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
     hipEvent_t stop = ctx->time_cull_stop;
     const uint32_t n = P.ModelCount;
     if (n == 0) {
+        ctx->cull_record_args = nullptr;
         if (visible_count) {
             if (stop != nullptr) hipExtLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, ctx->stream, nullptr, stop, 0, visible_count);
             else hipLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, ctx->stream, visible_count);
@@ -293,20 +326,26 @@ int launch_cull(ur_ctx* ctx, const uint32_t* constants, const ur_float4* bounds,
     }
     const uint32_t blocks = (n + 255u) / 256u;
     if (blocks == 1) {
+        ctx->cull_record_args = nullptr; // (one block keeps no masks)
         if (stop != nullptr) hipExtLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, nullptr, stop, 0, P);
         else hipLaunchKernelGGL(cull_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, P);
         UR_HIP_TRY(hipGetLastError());
         ctx->time_cull_carried = stop != nullptr;
         return UR_OK;
     }
-    if (visible_idx) {
+    if (visible_idx || P.store_flavour == 4u) {
         if (n > ctx->ws_instances) {
-            const int rc = ur_reserve(ctx, n);
+            const int rc = ur_reserve(ctx, n); // (a new workspace forgets the record)
             if (rc != UR_OK) return rc;
         }
         P.block_counts = ctx->block_counts;
         P.wave_masks = ctx->wave_masks;
     }
+    // UR_OPT_CULL_STORE = 4: the wave masks ARE the record of what this launch leaves in the command buffer; they describe the buffer the
+    // next launch meets if that launch is on the same buffer with the same count (and the caller keeps the promise of the option)
+    P.record_valid = (P.store_flavour == 4u && ctx->cull_record_args == indirect_args && ctx->cull_record_n == n) ? 1u : 0u;
+    ctx->cull_record_args = P.store_flavour == 4u ? indirect_args : nullptr;
+    ctx->cull_record_n = n;
     if (stop != nullptr && !visible_idx) hipExtLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, nullptr, stop, 0, P);
     else hipLaunchKernelGGL(cull_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, P);
     UR_HIP_TRY(hipGetLastError());

@@ -255,7 +255,7 @@ bool option_slot(int option, OptionSlot& o)
     case UR_OPT_LIGHTING_TILED_WAVES: o = {&O::tiled_waves, 4, 6, true}; return true;
     case UR_OPT_LIGHTING_LEAVE_CUS: o = {&O::leave_cus, 0, 128, false}; return true;
     case UR_OPT_RIDE_WALKERS: o = {&O::ride_walkers, 0, 16, false}; return true;
-    case UR_OPT_CULL_STORE: o = {&O::cull_store, 0, 3, false}; return true;
+    case UR_OPT_CULL_STORE: o = {&O::cull_store, 0, 4, false}; return true;
     case UR_OPT_LIGHTING_BALANCE: o = {&O::balance, 0, 1, false}; return true;
     case UR_OPT_BALANCE_POOL_16THS: o = {&O::balance_pool_16ths, 1, 8, false}; return true;
     case UR_OPT_BALANCE_CHUNK_SHIFT: o = {&O::balance_chunk_shift, 2, 6, false}; return true;
@@ -274,6 +274,7 @@ int ur_set_option(ur_ctx* ctx, int option, int value)
         return UR_EINVAL;
     }
     ctx->opt.*(o.field) = value;
+    if (option == UR_OPT_CULL_STORE) ctx->cull_record_args = nullptr; // (setting it - also to the value it has - forgets the record of flavour 4)
     return UR_OK;
 }
 
@@ -315,6 +316,7 @@ int ur_reserve(ur_ctx* ctx, uint32_t max_instances)
     if (ctx->block_counts) (void)hipFree(ctx->block_counts);
     if (ctx->wave_masks) (void)hipFree(ctx->wave_masks);
     ctx->block_counts = nullptr; ctx->wave_masks = nullptr; ctx->ws_instances = 0;
+    ctx->cull_record_args = nullptr;
     const size_t blocks = ((size_t)max_instances + 255u) / 256u;
     if (hipMalloc(&ctx->block_counts, blocks * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&ctx->wave_masks, blocks * 4u * sizeof(uint64_t)) != hipSuccess) {

@@ -29,6 +29,9 @@ struct ur_ctx {
     uint32_t* block_counts = nullptr; // one per 256-instance block
     uint64_t* wave_masks = nullptr;   // one per 64 instances
     uint32_t ws_instances = 0;
+    // UR_OPT_CULL_STORE = 4: wave_masks describes the InstanceCount words of this command buffer / count (the last multi-block launch's)
+    const void* cull_record_args = nullptr;
+    uint32_t cull_record_n = 0;
     // sRGB8 -> linear table (256 floats), uploaded once
     float* srgb_table = nullptr;
     int cu_count = 256;
