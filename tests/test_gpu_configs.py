@@ -130,6 +130,23 @@ def test_c5_cull_1m_against_the_8k_hzb(hotpath, oracle):
     assert np.array_equal(d_stats.cpu().numpy().view(np.uint32), ref_stats)
     assert ref_cnt > 1000 and ref_stats[0] > 0 and ref_stats[1] > 0, "both rejection paths and the visible path are exercised"
     assert np.all(np.diff(ref_vis.astype(np.int64)) > 0)
+    # the same million with the words' present values taken from the context's record (UR_OPT_CULL_STORE = 4): the launch above left no
+    # record (flavour 3), so the first launch reads the words; the second - another camera - runs from the record
+    from unclerenderer_amd import lib
+    hotpath.set_option(lib.UR_OPT_CULL_STORE, 4)
+    try:
+        d_bounds = to_device(bounds)
+        hotpath.cull_indirect_args(consts, d_bounds, hzb, lay, d_args, None, d_vis, d_cnt)
+        fc2 = hostmath.build_frame_constants("pica_pica", w, h)
+        consts2 = hostmath.pack_culling_constants(fc2.view, fc2.proj, n, True, lay.count, lay.width, lay.height, False)
+        ref_args2, _, ref_vis2, ref_cnt2 = oracle.cull_indirect_args(consts2, bounds, ref_hzb, lay.as_list(), ref_args)
+        hotpath.cull_indirect_args(consts2, d_bounds, hzb, lay, d_args, None, d_vis, d_cnt)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_args.cpu().numpy().view(np.uint32), ref_args2)
+        assert int(d_cnt.cpu()[0]) == ref_cnt2 and np.array_equal(d_vis.cpu().numpy().view(np.uint32)[:ref_cnt2], ref_vis2)
+        assert (ref_args2[:, 11] != ref_args[:, 11]).sum() > 100, "the second camera changes sides for many instances"
+    finally:
+        hotpath.set_option(lib.UR_OPT_CULL_STORE, 3)
 
 
 def test_c5_8k_gbuffer_lighting(hotpath, oracle):

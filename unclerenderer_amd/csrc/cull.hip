@@ -160,7 +160,12 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams C)
         const float4 bmin = sb[2u * tid], bmax = sb[2u * tid + 1u];
         frustumVisible = IsAabbVisible(C, make_float3(bmin.x, bmin.y, bmin.z), make_float3(bmax.x, bmax.y, bmax.z));
     }
-    if (C.HZBEnabled != 0) { // (launch-uniform)
+    if (SINGLE_BLOCK) { // a few instances (the frame's own cull: 25 commands): lane by lane, no barrier in the way of the one workgroup's latency
+        if (active && frustumVisible && C.HZBEnabled != 0) {
+            const float4 bmin = sb[2u * tid], bmax = sb[2u * tid + 1u];
+            occluded = IsOccluded(C, make_float3(bmin.x, bmin.y, bmin.z), make_float3(bmax.x, bmax.y, bmax.z));
+        }
+    } else if (C.HZBEnabled != 0) { // (launch-uniform)
         // The occlusion test (eight corners projected with IEEE divides, a mip choice, four taps) is several times the frustum test, and
         // only what the frustum lets through takes it - one instance in nine of the 1 M stress set: run lane by lane, every wave paid for
         // it at a ninth of its lanes. The block's survivors are packed first (ballots + popcounts, their indices in LDS) and tested
