@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void taa_strip_kernel(TaaParams p)
 #pragma unroll
     for (int k = 0; k < kStripRows + 2; ++k) c[k] = cur[frame_row((int)r0 + k - 1) + cx];
 #pragma unroll
-    for (int k = 0; k < kStripRows; ++k) hist[k] = his[(size_t)min(r0 + (uint32_t)k, p.rows - 1u) * p.W + cx];
+    for (int k = 0; k < kStripRows; ++k) hist[k] = __builtin_nontemporal_load(his + (size_t)min(r0 + (uint32_t)k, p.rows - 1u) * p.W + cx); // read once
     const uint32_t nrows = min((uint32_t)kStripRows, p.rows - r0);
     auto reduce_row = [&](int k) {
         return row_minmax(c[k], __builtin_amdgcn_readlane(halo.x, k), __builtin_amdgcn_readlane(halo.y, k),
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void taa_strip_kernel(TaaParams p)
             }
             half2_t o0, o1;
             o0.x = (_Float16)b[0]; o0.y = (_Float16)b[1]; o1.x = (_Float16)b[2]; o1.y = c1.y; // alpha of the current texel
-            out[(size_t)r * p.W + px] = u32x2_t{as_u(o0), as_u(o1)};
+            __builtin_nontemporal_store(u32x2_t{as_u(o0), as_u(o1)}, out + (size_t)r * p.W + px);
         }
         mPrev = mCur; mCur = mNext;
     }

@@ -85,14 +85,14 @@ __global__ __launch_bounds__(256) void tonemap_pairs_kernel(TonemapParams p)
     const u32x4_t* src = reinterpret_cast<const u32x4_t*>(p.hdr);
     u32x4_t v[kPairTrips];
 #pragma unroll
-    for (uint32_t k = 0; k < kPairTrips; ++k) v[k] = src[min(pair0 + k * 64u, npairs - 1u)];
+    for (uint32_t k = 0; k < kPairTrips; ++k) v[k] = __builtin_nontemporal_load(src + min(pair0 + k * 64u, npairs - 1u)); // read once
 #pragma unroll
     for (uint32_t k = 0; k < kPairTrips; ++k) {
         const uint32_t pr = pair0 + k * 64u;
         if (pr < npairs) {
             union { u32x2_t u; half4_t h; } a, b;
             a.u = u32x2_t{v[k].x, v[k].y}; b.u = u32x2_t{v[k].z, v[k].w};
-            reinterpret_cast<u32x2_t*>(p.out)[pr] = u32x2_t{tonemap_pixel(p, finalExposure, a.h), tonemap_pixel(p, finalExposure, b.h)};
+            __builtin_nontemporal_store(u32x2_t{tonemap_pixel(p, finalExposure, a.h), tonemap_pixel(p, finalExposure, b.h)}, reinterpret_cast<u32x2_t*>(p.out) + pr);
         }
     }
 }
