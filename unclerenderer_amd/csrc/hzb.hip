@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
         float* d0 = p.dst[0];
         const uint32_t x0 = x1 * 2u, y0 = y1 * 2u;
         if (p.pair_ok && x0 + 1u < p.W[0]) { // 8-byte aligned pair
-            *reinterpret_cast<float2*>(d0 + (size_t)y0 * p.W[0] + x0) = make_float2(v0[0][0], v0[0][1]);
-            if (y0 + 1u < p.H[0]) *reinterpret_cast<float2*>(d0 + (size_t)(y0 + 1u) * p.W[0] + x0) = make_float2(v0[1][0], v0[1][1]);
+            typedef float hf32x2_t __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(hf32x2_t{v0[0][0], v0[0][1]}, reinterpret_cast<hf32x2_t*>(d0 + (size_t)y0 * p.W[0] + x0)); // written once, read by a later launch
+            if (y0 + 1u < p.H[0]) __builtin_nontemporal_store(hf32x2_t{v0[1][0], v0[1][1]}, reinterpret_cast<hf32x2_t*>(d0 + (size_t)(y0 + 1u) * p.W[0] + x0));
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)

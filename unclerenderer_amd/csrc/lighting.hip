@@ -824,14 +824,16 @@ __device__ __forceinline__ uint32_t dyn_claim(P kp, uint32_t* work, uint32_t* dy
 }
 
 // WPB waves per workgroup, one workgroup per CU (two of 10 waves at 96 VGPRs were tried: the loop spills).
-// HDR stores are write-through (sc1): in a loop of its own the launch takes the same time as with plain or nontemporal stores, but
-// nothing of it is left dirty in L2 for the end of the launch to write back, and the NEXT launch of the frame starts 0.6-0.9 us
-// earlier (frame 80.0-80.4 -> 79.4-79.6 us, four same-box pairs, round 2).
+// HDR stores are write-through AND nontemporal (sc1 nt). Write-through alone (round 2): the launch takes the same time as with plain
+// or nontemporal stores, but nothing of it is left dirty in L2 for the end of the launch to write back, and the NEXT launch of the frame
+// starts 0.6-0.9 us earlier. Both hints together (round 4; either alone changes nothing): the 66 MB written once neither stay dirty nor
+// take cache lines from the gathers' working set - 4K alone 68.8 -> 66.6 us, the dispatch inside the frame 72.3 -> 70.8, frame 76.7 -> 75.4
+// (profiles/r04_priority.txt; the plain streaming kernel gains the same way from the hints: 64.8 -> 60.8 us).
 __device__ __forceinline__ void store_hdr(void* base, uint32_t byte_offset, uint32_t lo, uint32_t hi)
 {
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const u32x2_t v = {lo, hi};
-    asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(byte_offset), "v"(v), "s"(base) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc1 nt" ::"v"(byte_offset), "v"(v), "s"(base) : "memory");
 }
 
 // The wide launch of a held-back HZB chain, taken along by the lighting workgroups (ur_defer_hzb_tail(ctx, 2)): workgroup g's
