@@ -12,6 +12,7 @@
 // Built with -ffp-contract=off; the only arithmetic is fminf.
 
 #include "ur_internal.h"
+#include "ur_device.h"
 #include "hzb_tail.h"
 #include "hzb_wide.h"
 
@@ -61,9 +62,8 @@ __global__ __launch_bounds__(256) void hzb_reduce4_kernel(HzbDispatch p)
         float* d0 = p.dst[0];
         const uint32_t x0 = x1 * 2u, y0 = y1 * 2u;
         if (p.pair_ok && x0 + 1u < p.W[0]) { // 8-byte aligned pair
-            typedef float hf32x2_t __attribute__((ext_vector_type(2)));
-            __builtin_nontemporal_store(hf32x2_t{v0[0][0], v0[0][1]}, reinterpret_cast<hf32x2_t*>(d0 + (size_t)y0 * p.W[0] + x0)); // written once, read by a later launch
-            if (y0 + 1u < p.H[0]) __builtin_nontemporal_store(hf32x2_t{v0[1][0], v0[1][1]}, reinterpret_cast<hf32x2_t*>(d0 + (size_t)(y0 + 1u) * p.W[0] + x0));
+            ur::store_once_b64(d0 + (size_t)y0 * p.W[0] + x0, ur::once_u32x2_t{__float_as_uint(v0[0][0]), __float_as_uint(v0[0][1])}); // written once, read by a later launch
+            if (y0 + 1u < p.H[0]) ur::store_once_b64(d0 + (size_t)(y0 + 1u) * p.W[0] + x0, ur::once_u32x2_t{__float_as_uint(v0[1][0]), __float_as_uint(v0[1][1])});
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)

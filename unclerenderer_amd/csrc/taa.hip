@@ -15,6 +15,7 @@
 // two rounds: 37.0 us = 5.4 TB/s.
 
 #include "ur_internal.h"
+#include "ur_device.h"
 
 namespace {
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void taa_strip_kernel(TaaParams p)
             }
             half2_t o0, o1;
             o0.x = (_Float16)b[0]; o0.y = (_Float16)b[1]; o1.x = (_Float16)b[2]; o1.y = c1.y; // alpha of the current texel
-            __builtin_nontemporal_store(u32x2_t{as_u(o0), as_u(o1)}, out + (size_t)r * p.W + px);
+            ur::store_once_b64(out + (size_t)r * p.W + px, ur::once_u32x2_t{as_u(o0), as_u(o1)});
         }
         mPrev = mCur; mCur = mNext;
     }

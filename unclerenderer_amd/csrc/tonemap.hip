@@ -8,6 +8,7 @@
 // same bits for the same pixel (the oracle comparison allows one LSB: exp2/log2 vs powf, v_rcp vs divide).
 
 #include "ur_internal.h"
+#include "ur_device.h"
 
 namespace {
 
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void tonemap_pairs_kernel(TonemapParams p)
         if (pr < npairs) {
             union { u32x2_t u; half4_t h; } a, b;
             a.u = u32x2_t{v[k].x, v[k].y}; b.u = u32x2_t{v[k].z, v[k].w};
-            __builtin_nontemporal_store(u32x2_t{tonemap_pixel(p, finalExposure, a.h), tonemap_pixel(p, finalExposure, b.h)}, reinterpret_cast<u32x2_t*>(p.out) + pr);
+            ur::store_once_b64(reinterpret_cast<u32x2_t*>(p.out) + pr, ur::once_u32x2_t{tonemap_pixel(p, finalExposure, a.h), tonemap_pixel(p, finalExposure, b.h)});
         }
     }
 }

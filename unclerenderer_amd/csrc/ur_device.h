@@ -7,6 +7,14 @@
 
 namespace ur {
 
+// Eight bytes written ONCE by this launch and read by a later one: write-through and nontemporal (`sc1 nt`) - the line neither stays
+// dirty in L2 nor takes a place there (the HDR store of the lighting loop, csrc/lighting.hip: either hint alone changes nothing).
+typedef uint32_t once_u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_once_b64(void* p, once_u32x2_t v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+
 // Touch every 64-byte line of the kernarg segment (explicit arguments of BYTES bytes plus the hidden ones behind them)
 // with one batch of scalar loads and ONE wait. hipcc reads kernel parameters lazily, a few dwords at a time with a wait
 // after each group; at the start of a launch every new line is a scalar-cache miss, and a kernel with a dozen dependent
