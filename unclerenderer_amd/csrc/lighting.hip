@@ -150,6 +150,15 @@ __device__ __forceinline__ void st(void* base, uint32_t byte_offset, T v)
     *reinterpret_cast<UR_GLOBAL T*>((UR_GLOBAL char*)base + byte_offset) = v;
 }
 
+// HDR out of the per-tile kernel: written once, write-through + nontemporal like the streaming kernel's store (store_hdr below)
+__device__ __forceinline__ void st_hdr_once(void* base, uint32_t byte_offset, half4_t v)
+{
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t u;
+    __builtin_memcpy(&u, &v, 8);
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc1 nt" ::"v"(byte_offset), "v"(u), "s"(base) : "memory");
+}
+
 struct uint4u { uint32_t x, y, z, w; };  // 16 bytes loaded from an 8-byte-aligned address
 struct float3u { float x, y, z; };       // 12 bytes loaded from a 4-byte-aligned address
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
             asm volatile("" : "+v"(sky.x), "+v"(sky.y), "+v"(sky.z));
             half4_t o;
             o.x = (_Float16)sky.x; o.y = (_Float16)sky.y; o.z = (_Float16)sky.z; o.w = (_Float16)1.0f;
-            st<half4_t>(p.hdr, i * 8u, o);
+            st_hdr_once(p.hdr, i * 8u, o);
             return;
         }
         if (MODE == ur::UR_MODE_SKY) return;
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(256, WAVES) void lighting_kernel(LightingParams p)
     o.y = (_Float16)by;
     o.z = (_Float16)bz;
     o.w = (_Float16)bw;
-    st<half4_t>(p.hdr, i * 8u, o);
+    st_hdr_once(p.hdr, i * 8u, o);
 }
 
 // =====================================================================================================================
