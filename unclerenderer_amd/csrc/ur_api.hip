@@ -124,7 +124,7 @@ typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStre
 extern "C" {
 
 const char* ur_last_error(void) { return ur::g_error; }
-const char* ur_version(void) { return "unclerenderer_amd hotpath 0.4 (gfx950)"; }
+const char* ur_version(void) { return "unclerenderer_amd hotpath 0.5 (gfx950)"; }
 
 ur_ctx* ur_create(int device, void* stream)
 {
